@@ -1,0 +1,172 @@
+/* C ABI of the device-resident MPPI planning step for AMD MI355X (gfx950).
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point
+ * below names the reference interface it stands in for (paths relative to the
+ * reference tree).  A maintainer binds these with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success and a negative code on
+ * failure; the message is available from mppi_last_error() (thread local,
+ * valid until the next call on that thread).  Host pointers are copied before
+ * the call returns.  `stream` arguments take a hipStream_t (or NULL for the
+ * planner's own stream).  A planner is not re-entrant; distinct planners may
+ * be driven from distinct host threads.
+ */
+#ifndef MPPI_HIP_H
+#define MPPI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_MAXV 32
+#define MPPI_ABI_VERSION 1
+
+enum { MPPI_F32 = 0, MPPI_F64 = 1 };
+enum { MPPI_REWARD_DENSE = 0, MPPI_REWARD_SPARSE = 1, MPPI_REWARD_TRACKING = 2, MPPI_REWARD_COOLING = 3 };
+enum { MPPI_TAIL_REPEAT = 0, MPPI_TAIL_MEAN = 1 };
+enum {
+    MPPI_READ_RETURNS = 0,      /* double[K]            discounted return of every local sample        */
+    MPPI_READ_ACT_SEQ = 1,      /* double[H*M]          current act_sequence                            */
+    MPPI_READ_ARGMAX = 2,       /* int64[1]             global index of the best sample (first on ties) */
+    MPPI_READ_ACTIONS = 3,      /* double[K*H*M]        perturbed actions, sample-major (K,H,M)         */
+    MPPI_READ_NEXT_OBS = 4,     /* double[K*H*(2M+6)]   next_observations (needs cfg.dump)              */
+    MPPI_READ_REWARDS = 5,      /* double[K*H]          per-step rewards (needs cfg.dump)               */
+    MPPI_READ_STATUS = 6,       /* int32[1]             bit0: non-finite return seen                    */
+    MPPI_READ_RMAX = 7,         /* double[1]            best return                                      */
+    MPPI_READ_PARTIALS = 8      /* double[3+H*M]        this shard's (Rmax, argmax, den, num[H*M])      */
+};
+
+/* Flat model: links with hinge joints (welded bodies merged), the data the reference hands
+ * to its simulator through `load_model_from_path` (trajopt/envs/mujoco_env.py:39-40). */
+typedef struct mppi_model_desc {
+    char name[64];
+    int32_t nv;
+    int32_t frame_skip;
+    int32_t parent[MPPI_MAXV];
+    int32_t limited[MPPI_MAXV];
+    int32_t contact_link;
+    int32_t hand_link;
+    double h;
+    double pos[MPPI_MAXV][3];
+    double axis[MPPI_MAXV][3];
+    double mass[MPPI_MAXV];
+    double com[MPPI_MAXV][3];
+    double inertia[MPPI_MAXV][6];
+    double armature[MPPI_MAXV];
+    double damping[MPPI_MAXV];
+    double range_lo[MPPI_MAXV];
+    double range_hi[MPPI_MAXV];
+    double gear[MPPI_MAXV];
+    double ctrl_lo[MPPI_MAXV];
+    double ctrl_hi[MPPI_MAXV];
+    double dof_invweight[MPPI_MAXV];
+    double contact_pos[3];
+    double contact_radius;
+    double contact_plane_z;
+    double contact_margin;
+    double contact_invweight;
+    double hand_pos[3];
+    double solref_k;
+    double solref_b;
+    double solimp[5];
+} mppi_model_desc;
+
+/* Planner configuration: the constructor arguments of `MPPI.__init__`
+ * (trajopt/algos/mppi.py:16-54) that the device needs. */
+typedef struct mppi_planner_cfg {
+    int32_t K;             /* samples rolled out by this instance (this rank's shard)      */
+    int32_t H;             /* horizon                                                      */
+    int32_t dtype;         /* MPPI_F32 | MPPI_F64: arithmetic of the rollouts              */
+    int32_t device;        /* HIP device ordinal                                           */
+    int32_t reward_type;   /* MPPI_REWARD_*                                                */
+    int32_t default_act;   /* MPPI_TAIL_*                                                  */
+    int32_t k_offset;      /* global index of local sample 0 (sharded planners)            */
+    int32_t dump;          /* keep next_observations / rewards of every rollout            */
+    double kappa;
+    double gamma;
+    double sigma[MPPI_MAXV];   /* filter_coefs[0]                                          */
+    double beta[3];            /* filter_coefs[1:4]                                        */
+    double mean[MPPI_MAXV];
+} mppi_planner_cfg;
+
+typedef struct mppi_model mppi_model;
+typedef struct mppi_planner mppi_planner;
+
+int mppi_version(void);
+const char* mppi_last_error(void);
+
+/* Binds a model description to the kernels compiled for it; fails if no kernel was built
+ * for this model.  Stands in for `get_environment` + `MjSim` construction inside every
+ * rollout worker (trajopt/utils.py:66, trajopt/envs/mujoco_env.py:39-40). */
+int mppi_model_create(const mppi_model_desc* desc, mppi_model** out);
+void mppi_model_destroy(mppi_model* m);
+
+/* `MPPI.__init__` (trajopt/algos/mppi.py:16-54): allocates the device-resident state. */
+int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_planner** out);
+void mppi_planner_destroy(mppi_planner* p);
+
+/* `start_state` of `gather_paths_parallel` / `set_env_state` at the top of every rollout
+ * (trajopt/utils.py:76, trajopt/envs/reacher_env.py:151-160). */
+int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel, const double* target3,
+                         int32_t timestep);
+/* `base_act` of `gather_paths_parallel` = `MPPI.act_sequence` (trajopt/algos/mppi.py:47,113). */
+int mppi_set_base_actions(mppi_planner* p, const double* act_HxM);
+/* `reference` / `alpha` of the tracking and cooling rewards (trajopt/envs/reacher_env.py:60-79);
+ * ref may be NULL with T = 0. */
+int mppi_set_reference(mppi_planner* p, const double* ref_Tx3, int32_t T, double alpha);
+int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_type);
+
+/* Noise of `generate_perturbed_actions` (trajopt/utils.py:118-126).
+ * upload: raw N(0,1) draws made on the host, sample-major (K,H,M) -- the exact-comparison
+ * mode; the sigma scaling and the recursive filter run on the device.
+ * generate: counter-based Philox-4x32-10 stream keyed by seed, counter = global sample index. */
+int mppi_upload_noise(mppi_planner* p, const double* raw_KxHxM, void* stream);
+int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream);
+/* `act_list` of `do_env_rollout` (trajopt/utils.py:59): explicit action sequences (K,H,M);
+ * the next mppi_rollout uses them verbatim. */
+int mppi_upload_actions(mppi_planner* p, const double* act_KxHxM, void* stream);
+
+/* `do_env_rollout` + `score_trajectory` for all K samples (trajopt/utils.py:59-102,
+ * trajopt/algos/mppi.py:91-108). */
+int mppi_rollout(mppi_planner* p, void* stream);
+/* niter x [rollouts, `MPPI.update`] with the same noise, as the loop of `MPPI.train_step`
+ * (trajopt/algos/mppi.py:131-193, 56-65); single-rank form. */
+int mppi_iterate(mppi_planner* p, int32_t niter, void* stream);
+/* Sharded form of one iteration: rollouts + this shard's sufficient statistics
+ * (Rmax, argmax, sum S, sum S*eps) into the buffer at mppi_partials_ptr; after the caller
+ * has all-gathered the nranks buffers (rank order), mppi_merge applies `MPPI.update`.
+ * Replaces the result concatenation of `gather_paths_parallel` (trajopt/utils.py:158-161). */
+int mppi_local_partials(mppi_planner* p, void* stream);
+int mppi_partials_ptr(mppi_planner* p, void** device_ptr, size_t* bytes);
+int mppi_merge(mppi_planner* p, const void* gathered_device_ptr, int32_t nranks, void* stream);
+
+/* Horizon shift and tail fill of `MPPI.advance_time` (trajopt/algos/mppi.py:85-89);
+ * override_seq_HxM may be NULL (use the planner's own sequence). */
+int mppi_shift(mppi_planner* p, const double* override_seq_HxM, void* stream);
+
+int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);
+int mppi_synchronize(mppi_planner* p);
+
+/* One `env.step(a)` / `sim.forward()` of the real environment in fp64 on the device
+ * (trajopt/envs/reacher_env.py:43-85, 151-160).  obs_out holds 2*nv+6 values
+ * [qpos, qvel, hand(stale), target]; ref may be NULL. */
+int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const double* qvel, const double* target3,
+                  const double* act, int32_t timestep, int32_t reward_type, const double* ref_Tx3, int32_t T,
+                  double alpha, double* qpos_out, double* qvel_out, double* obs_out, double* reward_out);
+int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, double* hand3_out);
+
+/* `MPPI.update(paths)` for caller-supplied trajectories (trajopt/algos/mppi.py:56-65):
+ * actions (K,H,M), returns R (K) -> act_sequence (H,M), computed on the device. */
+int mppi_update_from_returns(const mppi_model* m, int32_t device, const double* act_KxHxM, const double* R,
+                             int32_t K, int32_t H, double kappa, double* act_seq_out);
+
+/* Philox-4x32-10 block function (host), for known-answer tests of the device generator. */
+void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,42 @@
+// Host build of the product's per-sample step (g++), used by CPU tests to check the
+// kernel arithmetic against the oracle before anything runs on a GPU.
+#include "../trajopt_amd/csrc/env_core.hpp"
+#include "../trajopt_amd/csrc/models_gen.hpp"
+
+using namespace mppi;
+
+template <class T, class MD>
+static void run(const double* q0, const double* v0, const double* target, const double* act, int H, int reward_type,
+                const double* ref, int t0, double alpha, double gamma, double* q_out, double* v_out, double* hand_out,
+                double* rewards, double* ret, int* sweeps) {
+    constexpr int NV = MD::NV;
+    T q[NV], v[NV];
+    for (int j = 0; j < NV; j++) { q[j] = T(q0[j]); v[j] = T(v0[j]); }
+    RewardParams<T> rp;
+    rp.type = reward_type; rp.alpha = T(alpha);
+    for (int c = 0; c < 3; c++) rp.target[c] = T(target[c]);
+    T R = 0, g = 1;
+    int ms = 0;
+    Vec3<T> hand = {{0, 0, 0}};
+    for (int t = 0; t < H; t++) {
+        T a[NV];
+        for (int j = 0; j < NV; j++) a[j] = T(act[t * NV + j]);
+        T rr[3] = {0, 0, 0};
+        if (ref) for (int c = 0; c < 3; c++) rr[c] = T(ref[3 * (t0 + t + 1) + c]);
+        T r = Env<T, MD>::step(q, v, a, rp, rr, hand, ms);
+        if (rewards) rewards[t] = double(r);
+        R += g * r; g *= T(gamma);
+    }
+    for (int j = 0; j < NV; j++) { q_out[j] = double(q[j]); v_out[j] = double(v[j]); }
+    for (int c = 0; c < 3; c++) hand_out[c] = double(hand.v[c]);
+    *ret = double(R); *sweeps = ms;
+}
+
+extern "C" void core_rollout(int f64, int model, const double* q0, const double* v0, const double* target,
+                             const double* act, int H, int reward_type, const double* ref, int t0, double alpha,
+                             double gamma, double* q_out, double* v_out, double* hand_out, double* rewards,
+                             double* ret, int* sweeps) {
+#define GO(T, MD) run<T, MD>(q0, v0, target, act, H, reward_type, ref, t0, alpha, gamma, q_out, v_out, hand_out, rewards, ret, sweeps)
+    if (model == 0) { if (f64) GO(double, Reacher7Dof); else GO(float, Reacher7Dof); }
+    else            { if (f64) GO(double, Reacher7DofFree); else GO(float, Reacher7DofFree); }
+}

@@ -1,0 +1,192 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's
+stored transitions.  Needs a GPU: run with `-m gpu`.
+
+Tolerances
+  fp64 kernels : 1e-10 absolute on states / rewards / returns (same algorithm, different
+                 operation order than the oracle)
+  fp32 kernels : relative 1e-4 on states and returns at H = 32 (the tolerance the planner
+                 is specified to), arg-max index exact
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_mppi
+
+pytestmark = pytest.mark.gpu
+
+FILTER = [np.ones(7), 0.25, 0.8, 0.0]
+
+
+@pytest.fixture(scope="module")
+def dev_model():
+    from trajopt_amd.device import DeviceModel
+    return DeviceModel.get("reacher_7dof")
+
+
+def _planner(dev_model, K, H, dtype, **kw):
+    from trajopt_amd.device import DevicePlanner
+    kw.setdefault("kappa", 25.0)
+    kw.setdefault("sigma", FILTER[0])
+    kw.setdefault("betas", FILTER[1:])
+    kw.setdefault("default_act", "mean")
+    return DevicePlanner(dev_model, K, H, dtype=dtype, **kw)
+
+
+def test_env_step_fp64_reproduces_stored_transitions(dev_model, transitions):
+    d = transitions
+    n = len(d["reward"])
+    worst = 0.0
+    for i in range(0, n, 3):
+        q2, v2, obs, r = dev_model.env_step(d["qp"][i], d["qv"][i], d["target"][i], d["act"][i], int(d["timestep"][i]))
+        worst = max(worst, np.abs(q2 - d["qp_next"][i]).max(), np.abs(v2 - d["qv_next"][i]).max(),
+                    np.abs(obs[:17] - d["obs_next"][i][:17]).max())
+        if d["file_id"][i] == 0:
+            assert abs(r - d["reward"][i]) < 1e-10
+    assert worst < 1e-10, worst
+
+
+def test_forward_hand(dev_model, oracle_sim):
+    rs = np.random.RandomState(0)
+    for _ in range(5):
+        q = rs.uniform(-1.5, 1.5, 7)
+        assert np.allclose(dev_model.forward_hand(q), oracle_sim.fk_hand(q), atol=1e-13)
+
+
+@pytest.mark.parametrize("start", ["rest", "limits"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_rollouts_K160_H32(dev_model, oracle_sim, transitions, dtype, start):
+    K, H = 160, 32
+    raw = ref_mppi.all_raw_normals(123, 40, 4, H, 7)
+    if start == "rest":
+        q0, v0, tgt, t0 = np.zeros(7), np.zeros(7), np.zeros(3), 0
+    else:   # step 50 of the stored dense agent: joints on their limits
+        i = int(np.where((transitions["file_id"] == 0) & (transitions["step"] == 50))[0][0])
+        q0, v0, tgt, t0 = transitions["qp"][i], transitions["qv"][i], transitions["target"][i], 50
+    base = np.zeros((H, 7))
+    act = base + ref_mppi.filter_noise(raw.copy(), FILTER)
+    R_o, nobs_o, rew_o = oracle_sim.rollout(q0, v0, tgt, t0, act, dump=True, nthreads=4)
+
+    p = _planner(dev_model, K, H, dtype, dump=True)
+    p.set_start_state(q0, v0, tgt, t0)
+    p.set_base_actions(base)
+    p.upload_noise(raw)
+    p.rollout()
+    R, nobs, rew, acts = p.returns(), p.next_observations(), p.rewards(), p.actions()
+    assert p.status() == 0
+    if dtype == "f64":
+        assert np.array_equal(acts, act)                     # filter arithmetic is bit-exact
+        assert np.abs(nobs - nobs_o).max() < 1e-10
+        assert np.abs(rew - rew_o).max() < 1e-10
+        assert np.abs(R - R_o).max() < 1e-10
+    else:
+        assert np.abs(acts - act).max() < 1e-6
+        scale = 1.0 + np.abs(nobs_o)
+        assert (np.abs(nobs - nobs_o) / scale).max() < 1e-4
+        assert (np.abs(R - R_o) / np.abs(R_o)).max() < 1e-4
+    assert int(np.argmax(R)) == int(np.argmax(R_o))
+    p.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_iterate_matches_update(dev_model, oracle_sim, dtype):
+    K, H = 160, 32
+    raw = ref_mppi.all_raw_normals(7, 40, 4, H, 7)
+    base = np.random.RandomState(1).randn(H, 7) * 0.3
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)
+    p = _planner(dev_model, K, H, dtype)
+    p.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, -0.05, 0.05]), 0)
+    p.set_base_actions(base)
+    p.upload_noise(raw)
+    p.iterate(1)
+    R = p.returns()
+    seq = p.act_sequence()
+    # the update, given the device's own returns and actions, against the numpy restatement
+    acts = base + (eps if dtype == "f64" else eps.astype(np.float32).astype(np.float64))
+    want = ref_mppi.update(acts, R, 25.0)
+    assert np.abs(seq - want).max() < (1e-11 if dtype == "f64" else 1e-6)
+    assert p.argmax() == int(np.argmax(R))
+    assert p.rmax() == R.max()
+    # end to end against the oracle's rollouts
+    R_o = oracle_sim.rollout(np.zeros(7), np.zeros(7), np.array([0.1, -0.05, 0.05]), 0, base + eps, nthreads=4)
+    want_o = ref_mppi.update(base + eps, R_o, 25.0)
+    assert p.argmax() == int(np.argmax(R_o))
+    tol = 1e-9 if dtype == "f64" else 2e-3      # weights are exp(25 * dR): fp32 return error is amplified
+    assert np.abs(seq - want_o).max() < tol
+    # second iteration uses the updated sequence with the same noise
+    p.iterate(1)
+    R2_o = oracle_sim.rollout(np.zeros(7), np.zeros(7), np.array([0.1, -0.05, 0.05]), 0, want_o + eps, nthreads=4)
+    want2 = ref_mppi.update(want_o + eps, R2_o, 25.0)
+    assert np.abs(p.act_sequence() - want2).max() < (1e-8 if dtype == "f64" else 5e-3)
+    p.close()
+
+
+def test_sharded_partials_merge_to_single_rank_result(dev_model):
+    import torch
+    K, H, G = 256, 16, 4
+    raw = ref_mppi.all_raw_normals(3, K, 1, H, 7)
+    base = np.zeros((H, 7))
+    full = _planner(dev_model, K, H, "f32")
+    full.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), 0)
+    full.set_base_actions(base)
+    full.upload_noise(raw)
+    full.iterate(1)
+    want = full.act_sequence()
+    shards = []
+    for r in range(G):
+        s = _planner(dev_model, K // G, H, "f32", k_offset=r * (K // G))
+        s.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), 0)
+        s.set_base_actions(base)
+        s.upload_noise(raw[r * (K // G):(r + 1) * (K // G)])
+        s.local_partials()
+        s.synchronize()
+        shards.append(s)
+    gathered = torch.from_numpy(np.stack([s.partials() for s in shards])).cuda()
+    torch.cuda.synchronize()
+    for s in shards:
+        s.merge(gathered.data_ptr(), G)
+        assert np.abs(s.act_sequence() - want).max() < 1e-12
+        assert s.argmax() == full.argmax()
+
+
+def test_shift_and_tail(dev_model):
+    H = 6
+    seq = np.random.RandomState(2).randn(H, 7)
+    for mode, mean in (("repeat", np.zeros(7)), ("mean", np.arange(7) * 0.1)):
+        p = _planner(dev_model, 64, H, "f32", default_act=mode, mean=mean)
+        p.set_base_actions(seq)
+        p.shift()
+        assert np.array_equal(p.act_sequence(), ref_mppi.shift(seq, mode, mean))
+        other = seq[::-1].copy()
+        p.shift(other)
+        assert np.array_equal(p.act_sequence(), ref_mppi.shift(other, mode, mean))
+        p.close()
+
+
+def test_update_from_returns(dev_model, planner_vectors):
+    v = planner_vectors
+    K, H, m = v["u_actions"].shape
+    acts = np.zeros((K, H, 7))
+    acts[:, :, :m] = v["u_actions"]
+    got = dev_model.update_from_returns(acts, v["u0_scores"], 25.0)
+    assert np.abs(got[:, :m] - v["u0_act_sequence"]).max() < 1e-13
+
+
+def test_philox_noise_statistics(dev_model):
+    K, H = 4096, 64
+    p = _planner(dev_model, K, H, "f32", sigma=np.ones(7), betas=(1.0, 0.0, 0.0))
+    p.set_base_actions(np.zeros((H, 7)))
+    p.generate_noise(2024)
+    z = p.actions()
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3
+    assert abs(np.mean(z ** 3)) < 2e-2 and abs(np.mean(z ** 4) - 3.0) < 5e-2
+    c = np.corrcoef(z.reshape(K, -1)[:, :20].T)
+    assert np.abs(c - np.eye(20)).max() < 0.08
+    p.generate_noise(2024)
+    assert np.array_equal(z, p.actions())          # counter based: same seed, same stream
+    p.generate_noise(2025)
+    assert not np.array_equal(z, p.actions())
+    # sharding does not change the stream: samples are addressed by their global index
+    s = _planner(dev_model, 1024, H, "f32", sigma=np.ones(7), betas=(1.0, 0.0, 0.0), k_offset=2048)
+    s.set_base_actions(np.zeros((H, 7)))
+    s.generate_noise(2024)
+    assert np.array_equal(s.actions(), z[2048:3072])

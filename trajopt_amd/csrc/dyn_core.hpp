@@ -1,0 +1,429 @@
+// Per-sample articulated-body step, specialised at compile time on the model.
+//
+// One call advances one sample by one physics substep; every quantity lives in
+// registers (the caller is one GPU lane).  The formulation is in link-local
+// coordinates -- velocities, forces and composite inertias are expressed in the
+// frame of the link they belong to -- so that the small wrist inertias are never
+// formed as differences of large world-frame terms; that is what keeps fp32
+// rollouts close to an fp64 simulator.  All model data are `static constexpr`
+// members of MD (see models_gen.hpp): loops are unrolled with compile-time
+// indices, so structural zeros vanish from the instruction stream.
+//
+// Replaces, for the planner's rollouts, the simulator call made by the
+// reference's `MujocoEnv.do_simulation` (trajopt/envs/mujoco_env.py:134-138).
+//
+// The same header compiles for the host (tests build it with g++ to compare
+// against the CPU oracle without a GPU).
+#pragma once
+#include <cmath>
+#include <type_traits>
+#include <utility>
+
+#if defined(__HIPCC__)
+#define MPPI_HD __host__ __device__ __forceinline__
+#else
+#define MPPI_HD inline __attribute__((always_inline))
+#endif
+
+namespace mppi {
+
+template <class F, int... Is>
+MPPI_HD void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+MPPI_HD void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+MPPI_HD void sincos_t(float x, float& s, float& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincosf(x, &s, &c);
+#else
+    s = std::sin(x); c = std::cos(x);
+#endif
+}
+MPPI_HD void sincos_t(double x, double& s, double& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(x, &s, &c);
+#else
+    s = std::sin(x); c = std::cos(x);
+#endif
+}
+MPPI_HD float sqrt_t(float x) { return sqrtf(x); }
+MPPI_HD double sqrt_t(double x) { return sqrt(x); }
+MPPI_HD float abs_t(float x) { return fabsf(x); }
+MPPI_HD double abs_t(double x) { return fabs(x); }
+
+constexpr int sym_idx(int i, int j) { return i == j ? i : i + j + 2; }   // xx yy zz xy xz yz
+
+template <class T> struct Vec3 { T v[3]; };
+
+template <class T> MPPI_HD Vec3<T> cross(const Vec3<T>& a, const Vec3<T>& b) {
+    return {{a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0]}};
+}
+template <class T> MPPI_HD Vec3<T> add(const Vec3<T>& a, const Vec3<T>& b) {
+    return {{a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2]}};
+}
+template <class T> MPPI_HD Vec3<T> scale(T s, const Vec3<T>& a) { return {{s * a.v[0], s * a.v[1], s * a.v[2]}}; }
+
+// rotation about coordinate axis A by angle (c, s): parent coordinates from child coordinates
+template <int A, class T> MPPI_HD Vec3<T> to_parent(T c, T s, const Vec3<T>& x) {
+    constexpr int U = (A + 1) % 3, W = (A + 2) % 3;
+    Vec3<T> y;
+    y.v[A] = x.v[A];
+    y.v[U] = c * x.v[U] - s * x.v[W];
+    y.v[W] = s * x.v[U] + c * x.v[W];
+    return y;
+}
+template <int A, class T> MPPI_HD Vec3<T> to_child(T c, T s, const Vec3<T>& x) {
+    constexpr int U = (A + 1) % 3, W = (A + 2) % 3;
+    Vec3<T> y;
+    y.v[A] = x.v[A];
+    y.v[U] = c * x.v[U] + s * x.v[W];
+    y.v[W] = c * x.v[W] - s * x.v[U];
+    return y;
+}
+
+// spatial inertia about a frame origin: mass, first moment h = m*c, rotational inertia I (sym 6)
+template <class T> struct SpInertia { T m; Vec3<T> h; T I[6]; };
+
+template <class T> MPPI_HD Vec3<T> sym_mul(const T (&I)[6], const Vec3<T>& w) {
+    return {{I[0] * w.v[0] + I[3] * w.v[1] + I[4] * w.v[2],
+             I[3] * w.v[0] + I[1] * w.v[1] + I[5] * w.v[2],
+             I[4] * w.v[0] + I[5] * w.v[1] + I[2] * w.v[2]}};
+}
+
+template <class T, class MD> struct Step {
+    static constexpr int NV = MD::NV;
+
+    struct Out {
+        Vec3<T> hand;        // end-effector site in world coordinates at the input q
+    };
+
+    template <int I> static MPPI_HD Vec3<T> pos_() { return {{T(MD::pos[I][0]), T(MD::pos[I][1]), T(MD::pos[I][2])}}; }
+    template <int I> static MPPI_HD Vec3<T> mc_() { return {{T(MD::mc[I][0]), T(MD::mc[I][1]), T(MD::mc[I][2])}}; }
+
+    // (q, v, ctrl) -> (q', v') in place.  max_sweeps bounds the active-set iteration.
+    static MPPI_HD void substep(T (&q)[NV], T (&qd)[NV], const T (&ctrl)[NV], Out& out, int& sweeps_out) {
+        T cs[NV], sn[NV];
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            T s, c;
+            sincos_t(q[i], s, c);
+            cs[i] = c;
+            sn[i] = (MD::axis_sign[i] > 0) ? s : -s;
+        });
+
+        // ---- world kinematics (end-effector site, contact sphere) ----------------------
+        // Rw[i] columns = link axes in world coordinates, pw[i] = link origin in world
+        Vec3<T> Rw[NV][3], pw[NV];
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            constexpr int p = MD::parent[i];
+            constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
+            Vec3<T> e0, e1, e2, pp;
+            if constexpr (p < 0) {
+                e0 = {{T(1), T(0), T(0)}}; e1 = {{T(0), T(1), T(0)}}; e2 = {{T(0), T(0), T(1)}};
+                pp = {{T(0), T(0), T(0)}};
+            } else {
+                e0 = Rw[p][0]; e1 = Rw[p][1]; e2 = Rw[p][2]; pp = pw[p];
+            }
+            const Vec3<T> E[3] = {e0, e1, e2};
+            pw[i] = add(pp, add(scale(T(MD::pos[i][0]), e0), add(scale(T(MD::pos[i][1]), e1), scale(T(MD::pos[i][2]), e2))));
+            Rw[i][A] = E[A];
+            Rw[i][U] = add(scale(cs[i], E[U]), scale(sn[i], E[W]));
+            Rw[i][W] = add(scale(cs[i], E[W]), scale(-sn[i], E[U]));
+        });
+        if constexpr (MD::hand_link >= 0) {
+            constexpr int L = MD::hand_link;
+            out.hand = add(pw[L], add(scale(T(MD::hand_pos[0]), Rw[L][0]),
+                                      add(scale(T(MD::hand_pos[1]), Rw[L][1]), scale(T(MD::hand_pos[2]), Rw[L][2]))));
+        }
+
+        // ---- bias forces: recursive Newton-Euler with zero joint acceleration ---------------
+        Vec3<T> om[NV], vl[NV], al[NV], ac[NV];       // angular/linear velocity, angular/linear spatial accel
+        Vec3<T> fn[NV], ff[NV];                       // moment about link origin, force
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            constexpr int p = MD::parent[i];
+            constexpr int A = MD::axis_id[i];
+            const Vec3<T> r = pos_<i>();
+            Vec3<T> w, v, a_w, a_v;
+            if constexpr (p < 0) {
+                w = {{T(0), T(0), T(0)}}; v = w; a_w = w; a_v = w;
+            } else {
+                w = to_child<A>(cs[i], sn[i], om[p]);
+                v = to_child<A>(cs[i], sn[i], add(vl[p], cross(om[p], r)));
+                a_w = to_child<A>(cs[i], sn[i], al[p]);
+                a_v = to_child<A>(cs[i], sn[i], add(ac[p], cross(al[p], r)));
+            }
+            // joint rate about axis A; velocity-product acceleration V x (S qd)
+            Vec3<T> sq = {{T(0), T(0), T(0)}};
+            sq.v[A] = T(MD::axis_sign[i]) * qd[i];
+            a_w = add(a_w, cross(w, sq));
+            a_v = add(a_v, cross(v, sq));
+            w.v[A] += sq.v[A];
+            om[i] = w; vl[i] = v; al[i] = a_w; ac[i] = a_v;
+            const T m = T(MD::mass[i]);
+            const Vec3<T> h = mc_<i>();
+            const T IO[6] = {T(MD::IO[i][0]), T(MD::IO[i][1]), T(MD::IO[i][2]), T(MD::IO[i][3]), T(MD::IO[i][4]), T(MD::IO[i][5])};
+            const Vec3<T> lV = add(scale(m, v), cross(w, h));
+            const Vec3<T> nV = add(sym_mul(IO, w), cross(h, v));
+            const Vec3<T> lA = add(scale(m, a_v), cross(a_w, h));
+            const Vec3<T> nA = add(sym_mul(IO, a_w), cross(h, a_v));
+            fn[i] = add(nA, add(cross(w, nV), cross(v, lV)));
+            ff[i] = add(lA, cross(w, lV));
+        });
+        T bias[NV];
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = NV - 1 - Ic;
+            constexpr int p = MD::parent[i];
+            constexpr int A = MD::axis_id[i];
+            bias[i] = T(MD::axis_sign[i]) * fn[i].v[A];
+            if constexpr (p >= 0) {
+                const Vec3<T> r = pos_<i>();
+                const Vec3<T> f = to_parent<A>(cs[i], sn[i], ff[i]);
+                const Vec3<T> n = to_parent<A>(cs[i], sn[i], fn[i]);
+                ff[p] = add(ff[p], f);
+                fn[p] = add(fn[p], add(n, cross(r, f)));
+            }
+        });
+
+        // ---- joint-space inertia: composite rigid bodies in link coordinates ------------------
+        SpInertia<T> Ic_[NV];
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            Ic_[i].m = T(MD::mass[i]);
+            Ic_[i].h = mc_<i>();
+            static_for<6>([&](auto En) { Ic_[i].I[En] = T(MD::IO[i][En]); });
+        });
+        T M[NV][NV];     // lower triangle used: M[i][j], i >= j
+        static_for<NV>([&](auto Icn) {
+            constexpr int i = NV - 1 - Icn;
+            constexpr int p = MD::parent[i];
+            constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
+            // column i of M: force produced by unit acceleration of joint i on composite body i
+            {
+                Vec3<T> ea = {{T(0), T(0), T(0)}};
+                constexpr T sgn = T(MD::axis_sign[i]);
+                ea.v[A] = sgn;
+                Vec3<T> n = {{sgn * Ic_[i].I[sym_idx(0, A)], sgn * Ic_[i].I[sym_idx(1, A)], sgn * Ic_[i].I[sym_idx(2, A)]}};
+                Vec3<T> f = cross(ea, Ic_[i].h);
+                M[i][i] = Ic_[i].I[sym_idx(A, A)] + T(MD::armature[i]);
+                walk_up<i, i>(cs, sn, n, f, M);
+            }
+            if constexpr (p >= 0) {
+                // express composite i in the parent frame and add it to the parent's composite
+                const T c = cs[i], s = sn[i];
+                const T* I = Ic_[i].I;
+                const Vec3<T> h = to_parent<A>(c, s, Ic_[i].h);
+                T J[6];
+                const T cc = c * c, ss = s * s, sc = s * c;
+                const T Iuu = I[sym_idx(U, U)], Iww = I[sym_idx(W, W)], Iuw = I[sym_idx(U, W)];
+                const T Iau = I[sym_idx(A, U)], Iaw = I[sym_idx(A, W)];
+                J[sym_idx(A, A)] = I[sym_idx(A, A)];
+                J[sym_idx(A, U)] = c * Iau - s * Iaw;
+                J[sym_idx(A, W)] = s * Iau + c * Iaw;
+                J[sym_idx(U, U)] = cc * Iuu - T(2) * sc * Iuw + ss * Iww;
+                J[sym_idx(W, W)] = ss * Iuu + T(2) * sc * Iuw + cc * Iww;
+                J[sym_idx(U, W)] = sc * (Iuu - Iww) + (cc - ss) * Iuw;
+                const Vec3<T> r = pos_<i>();
+                const T m = Ic_[i].m;
+                const T rr = r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2];
+                const T rh = r.v[0] * h.v[0] + r.v[1] * h.v[1] + r.v[2] * h.v[2];
+                const T dg = m * rr + T(2) * rh;
+                Ic_[p].m += m;
+                Ic_[p].h = add(Ic_[p].h, add(h, scale(m, r)));
+                static_for<3>([&](auto ax) {
+                    constexpr int a = ax;
+                    Ic_[p].I[sym_idx(a, a)] += J[sym_idx(a, a)] + dg - m * r.v[a] * r.v[a] - T(2) * r.v[a] * h.v[a];
+                });
+                Ic_[p].I[3] += J[3] - m * r.v[0] * r.v[1] - r.v[0] * h.v[1] - h.v[0] * r.v[1];
+                Ic_[p].I[4] += J[4] - m * r.v[0] * r.v[2] - r.v[0] * h.v[2] - h.v[0] * r.v[2];
+                Ic_[p].I[5] += J[5] - m * r.v[1] * r.v[2] - r.v[1] * h.v[2] - h.v[1] * r.v[2];
+            }
+        });
+
+        // ---- smooth force -------------------------------------------------------------------
+        T fs[NV];
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            T u = ctrl[i];
+            u = u < T(MD::ctrl_lo[i]) ? T(MD::ctrl_lo[i]) : u;
+            u = u > T(MD::ctrl_hi[i]) ? T(MD::ctrl_hi[i]) : u;
+            fs[i] = T(MD::gear[i]) * u - T(MD::damping[i]) * qd[i] - bias[i];
+        });
+
+        // ---- soft constraint rows ------------------------------------------------------------
+        T fc[NV];
+        static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
+        int sweeps = 0;
+        bool any_row = false;
+        T Dl[NV], arl[NV], sg[NV];          // limit rows: weight (0 = no row), reference accel, sign of J
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            Dl[i] = T(0); arl[i] = T(0); sg[i] = T(1);
+            if constexpr (MD::limited[i] != 0) {
+                const T lo = q[i] - T(MD::range_lo[i]);
+                const T hi = T(MD::range_hi[i]) - q[i];
+                const bool blo = lo < T(0), bhi = hi < T(0);
+                if (blo || bhi) {
+                    const T pos = blo ? lo : hi;
+                    sg[i] = blo ? T(1) : T(-1);
+                    row_constants(pos, sg[i] * qd[i], T(MD::dof_invweight[i]), Dl[i], arl[i]);
+                    any_row = true;
+                }
+            }
+        });
+        T Jc[NV], Dc = T(0), arc = T(0);
+        static_for<NV>([&](auto Ic) { Jc[Ic] = T(0); });
+        if constexpr (MD::contact_link >= 0) {
+            constexpr int L = MD::contact_link;
+            const Vec3<T> cw = add(pw[L], add(scale(T(MD::contact_pos[0]), Rw[L][0]),
+                                              add(scale(T(MD::contact_pos[1]), Rw[L][1]), scale(T(MD::contact_pos[2]), Rw[L][2]))));
+            const T dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
+            if (dist < T(MD::contact_margin)) {
+                T vel = T(0);
+                contact_jac<L>(Rw, pw, cw, Jc);
+                static_for<NV>([&](auto Ic) { vel += Jc[Ic] * qd[Ic]; });
+                row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), Dc, arc);
+                any_row = true;
+            }
+        }
+
+        if (any_row) {
+            bool actl[NV], actc = Dc > T(0);
+            static_for<NV>([&](auto Ic) { actl[Ic] = Dl[Ic] > T(0); });
+            T acc[NV], resl[NV], resc = T(0);
+            for (;;) {
+                sweeps++;
+                T A[NV][NV];
+                static_for<NV>([&](auto Ic) {
+                    constexpr int i = Ic;
+                    static_for<i + 1>([&](auto Jn) { A[i][Jn] = M[i][Jn] + (actc ? Dc * Jc[i] * Jc[Jn] : T(0)); });
+                    A[i][i] += actl[i] ? Dl[i] : T(0);
+                    acc[i] = fs[i] + (actl[i] ? sg[i] * Dl[i] * arl[i] : T(0)) + (actc ? Dc * arc * Jc[i] : T(0));
+                });
+                chol_solve(A, acc);
+                bool changed = false;
+                static_for<NV>([&](auto Ic) {
+                    constexpr int i = Ic;
+                    if constexpr (MD::limited[i] != 0) {
+                        resl[i] = sg[i] * acc[i] - arl[i];
+                        const bool a = (Dl[i] > T(0)) && (resl[i] < T(0));
+                        changed |= (a != actl[i]);
+                        actl[i] = a;
+                    }
+                });
+                if constexpr (MD::contact_link >= 0) {
+                    T ja = T(0);
+                    static_for<NV>([&](auto Ic) { ja += Jc[Ic] * acc[Ic]; });
+                    resc = ja - arc;
+                    const bool a = (Dc > T(0)) && (resc < T(0));
+                    changed |= (a != actc);
+                    actc = a;
+                }
+                if (!changed || sweeps >= 12) break;
+            }
+            static_for<NV>([&](auto Ic) {
+                constexpr int i = Ic;
+                if constexpr (MD::limited[i] != 0) fc[i] = actl[i] ? -sg[i] * Dl[i] * resl[i] : T(0);
+            });
+            if constexpr (MD::contact_link >= 0) {
+                if (actc) {
+                    const T f = -Dc * resc;
+                    static_for<NV>([&](auto Ic) { fc[Ic] += Jc[Ic] * f; });
+                }
+            }
+        }
+        sweeps_out = sweeps;
+
+        // ---- semi-implicit Euler with implicit joint damping ----------------------------------
+        T qacc[NV];
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            M[i][i] += T(MD::H) * T(MD::damping[i]);
+            qacc[i] = fs[i] + fc[i];
+        });
+        chol_solve(M, qacc);
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            qd[i] = qd[i] + T(MD::H) * qacc[i];
+            q[i] = q[i] + T(MD::H) * qd[i];
+        });
+    }
+
+    // carry the force (n about origin of link I, f) of column COL up the tree, filling M[COL][ancestor]
+    template <int COL, int I>
+    static MPPI_HD void walk_up(const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& n, const Vec3<T>& f, T (&M)[NV][NV]) {
+        constexpr int p = MD::parent[I];
+        if constexpr (p >= 0) {
+            constexpr int A = MD::axis_id[I];
+            const Vec3<T> r = pos_<I>();
+            const Vec3<T> fp = to_parent<A>(cs[I], sn[I], f);
+            const Vec3<T> np = add(to_parent<A>(cs[I], sn[I], n), cross(r, fp));
+            M[COL][p] = T(MD::axis_sign[p]) * np.v[MD::axis_id[p]];
+            walk_up<COL, p>(cs, sn, np, fp, M);
+        }
+    }
+
+    // impedance, stiffness/damping reference and regulariser of one constraint row
+    static MPPI_HD void row_constants(T x, T vel, T invweight, T& D, T& aref) {
+        const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]), width = T(MD::solimp[2]), mid = T(MD::solimp[3]);
+        static_assert(MD::solimp[4] == 2.0, "impedance power other than 2 is not compiled in");
+        const T u = abs_t(x) / width;
+        T imp = dmax;
+        if (u < T(1)) {
+            T y;
+            if (u <= mid) y = u * u / mid;
+            else { const T w = T(1) - u; y = T(1) - w * w / (T(1) - mid); }
+            imp = d0 + y * (dmax - d0);
+        }
+        aref = -T(MD::solref_b) * vel - T(MD::solref_k) * imp * x;
+        D = imp / ((T(1) - imp) * invweight);
+    }
+
+    // d(z of contact sphere centre)/dq for the ancestors of link L
+    template <int L>
+    static MPPI_HD void contact_jac(const Vec3<T> (&Rw)[NV][3], const Vec3<T> (&pw)[NV], const Vec3<T>& cw, T (&Jc)[NV]) {
+        constexpr int A = MD::axis_id[L];
+        const Vec3<T>& a = Rw[L][A];
+        const T rx = cw.v[0] - pw[L].v[0], ry = cw.v[1] - pw[L].v[1];
+        Jc[L] = T(MD::axis_sign[L]) * (a.v[0] * ry - a.v[1] * rx);
+        if constexpr (MD::parent[L] >= 0) contact_jac<MD::parent[L]>(Rw, pw, cw, Jc);
+    }
+
+    // in-place Cholesky of the lower triangle of A, then solve A x = b (b overwritten)
+    static MPPI_HD void chol_solve(T (&A)[NV][NV], T (&b)[NV]) {
+        T inv[NV];
+        static_for<NV>([&](auto Jn) {
+            constexpr int j = Jn;
+            T s = A[j][j];
+            static_for<j>([&](auto Kn) { s -= A[j][Kn] * A[j][Kn]; });
+            const T d = sqrt_t(s);
+            inv[j] = T(1) / d;
+            A[j][j] = d;
+            static_for<NV - 1 - j>([&](auto In) {
+                constexpr int i = j + 1 + In;
+                T t = A[i][j];
+                static_for<j>([&](auto Kn) { t -= A[i][Kn] * A[j][Kn]; });
+                A[i][j] = t * inv[j];
+            });
+        });
+        static_for<NV>([&](auto In) {
+            constexpr int i = In;
+            T t = b[i];
+            static_for<i>([&](auto Kn) { t -= A[i][Kn] * b[Kn]; });
+            b[i] = t * inv[i];
+        });
+        static_for<NV>([&](auto In) {
+            constexpr int i = NV - 1 - In;
+            T t = b[i];
+            static_for<NV - 1 - i>([&](auto Kn) { constexpr int k = i + 1 + Kn; t -= A[k][i] * b[k]; });
+            b[i] = t * inv[i];
+        });
+    }
+};
+
+}  // namespace mppi

@@ -1,0 +1,57 @@
+// One env.step of the reacher family on top of the substep: FRAME_SKIP physics
+// substeps with the action held, then the reward of
+// `Reacher7DOFEnv._step` (trajopt/envs/reacher_env.py:43-85).
+//
+// The end-effector position that enters the reward and the observation is the
+// one evaluated at the configuration *before* the last substep's integration:
+// the reference reads the simulator's derived site position right after
+// `sim.step()`, which still belongs to the pre-integration configuration.
+#pragma once
+#include "dyn_core.hpp"
+
+namespace mppi {
+
+enum RewardType : int { REWARD_DENSE = 0, REWARD_SPARSE = 1, REWARD_TRACKING = 2, REWARD_COOLING = 3 };
+
+template <class T> struct RewardParams {
+    int type;          // RewardType
+    T alpha;           // cooling blend (reacher_env.py:79)
+    T target[3];
+};
+
+template <class T, class MD> struct Env {
+    static constexpr int NV = MD::NV;
+    using S = Step<T, MD>;
+
+    // ref_row: reference[env_timestep_after_step] (3 values) or nullptr
+    static MPPI_HD T reward(const RewardParams<T>& rp, const Vec3<T>& hand, const T (&qd)[NV], const T* ref_row) {
+        T vv = T(0);
+        static_for<NV>([&](auto Ic) { vv += qd[Ic] * qd[Ic]; });
+        const T vn = sqrt_t(vv);
+        const T dx = hand.v[0] - rp.target[0], dy = hand.v[1] - rp.target[1], dz = hand.v[2] - rp.target[2];
+        const T dist = sqrt_t(dx * dx + dy * dy + dz * dz);
+        const T sparse = dist < T(0.025) ? T(100) : (dist > T(0.8) ? T(-100) : T(-10));
+        if (rp.type == REWARD_SPARSE) return sparse;
+        if (rp.type == REWARD_TRACKING || rp.type == REWARD_COOLING) {
+            const T ex = hand.v[0] - ref_row[0], ey = hand.v[1] - ref_row[1], ez = hand.v[2] - ref_row[2];
+            const T track = T(-10) * sqrt_t(ex * ex + ey * ey + ez * ez) - T(0.25) * vn;
+            if (rp.type == REWARD_TRACKING) return track;
+            return rp.alpha * track + (T(1) - rp.alpha) * sparse;
+        }
+        return T(-10) * dist - T(0.25) * vn;
+    }
+
+    static MPPI_HD T step(T (&q)[NV], T (&qd)[NV], const T (&act)[NV], const RewardParams<T>& rp, const T* ref_row,
+                          Vec3<T>& hand, int& max_sweeps) {
+        typename S::Out o;
+        for (int s = 0; s < MD::FRAME_SKIP; s++) {
+            int sw;
+            S::substep(q, qd, act, o, sw);
+            max_sweeps = sw > max_sweeps ? sw : max_sweeps;
+        }
+        hand = o.hand;
+        return reward(rp, hand, qd, ref_row);
+    }
+};
+
+}  // namespace mppi

@@ -1,0 +1,965 @@
+// Device-resident MPPI planning step for MI355X (gfx950): kernels and C ABI.
+//
+// Kernels (one lane = one sampled action sequence; wave = 64 samples):
+//   noise_upload_kernel / noise_philox_kernel   sigma scaling + recursive 3-tap filter, writes eps[t][j][k]
+//   rollout_kernel<T, MD>                       H env steps x FRAME_SKIP substeps, fused reward + discounted return
+//   weights_kernel<T>                           max / arg-max over K, S_k = exp(kappa (R_k - Rmax)), sum S
+//   wsum_kernel<T>                              sum_k S_k eps[t][j][k] for every (t, j)
+//   merge_kernel                                rank-ordered merge of shard statistics, writes act_sequence
+//   shift_kernel                                receding-horizon shift + tail fill
+//   env_step_kernel<MD>                         one fp64 env.step for the real environment
+//
+// Layout in HBM: eps is stored step-major, sample-minor ([H][M][K]) so that the 64 lanes of
+// a wave read 64 consecutive values per (t, j); returns are [K]; act_sequence is [H][M] fp64.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mppi_hip.h"
+#include "env_core.hpp"
+#include "models_gen.hpp"
+
+using namespace mppi;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device-side state
+// ------------------------------------------------------------------------------------------
+struct DevState {
+    double q[MPPI_MAXV];
+    double v[MPPI_MAXV];
+    double target[3];
+    double alpha;
+    int timestep;
+    int ref_len;
+};
+
+// ------------------------------------------------------------------------------------------
+// Philox-4x32-10
+// ------------------------------------------------------------------------------------------
+MPPI_HD void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+MPPI_HD void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+extern "C" void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    philox4x32_10(c, key[0], key[1]);
+    for (int i = 0; i < 4; i++) out[i] = c[i];
+}
+
+// two uniforms -> two N(0,1) (Box-Muller)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.28318530717958647692f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// ------------------------------------------------------------------------------------------
+// noise kernels: one lane per sample, recursion along t in registers
+// eps[t] = b0*sigma*z[t] + b1*eps[t-1] + b2*eps[t-2] for t >= 2 (rows 0, 1 unfiltered); separate
+// roundings for every product and sum so the fp64 path reproduces the host arithmetic bit for bit
+// ------------------------------------------------------------------------------------------
+struct FilterCoefs {
+    double sigma[MPPI_MAXV];
+    double b0, b1, b2;
+};
+
+template <class T, int NV>
+__global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restrict__ raw, int K, int H, FilterCoefs fc,
+                                                          int filter, T* __restrict__ eps) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    double e1[NV], e2[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) e1[j] = e2[j] = 0.0;
+    for (int t = 0; t < H; t++) {
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            double e = raw[((size_t)k * H + t) * NV + j];
+            if (filter) {
+                e = __dmul_rn(e, fc.sigma[j]);
+                if (t >= 2) e = __dadd_rn(__dadd_rn(__dmul_rn(fc.b0, e), __dmul_rn(fc.b1, e1[j])), __dmul_rn(fc.b2, e2[j]));
+            }
+            e2[j] = e1[j];
+            e1[j] = e;
+            eps[((size_t)t * NV + j) * K + k] = T(e);
+        }
+    }
+}
+
+template <class T, int NV>
+__global__ void __launch_bounds__(64) noise_philox_kernel(int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
+                                                          FilterCoefs fc, T* __restrict__ eps) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    constexpr int CALLS = (NV + 3) / 4;
+    double e1[NV], e2[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) e1[j] = e2[j] = 0.0;
+    for (int t = 0; t < H; t++) {
+        float z[CALLS * 4];
+#pragma unroll
+        for (int c = 0; c < CALLS; c++) {
+            uint32_t ctr[4] = {(uint32_t)(k_offset + k), (uint32_t)t, (uint32_t)c, 0u};
+            philox4x32_10(ctr, seed_lo, seed_hi);
+            box_muller(ctr[0], ctr[1], z[4 * c + 0], z[4 * c + 1]);
+            box_muller(ctr[2], ctr[3], z[4 * c + 2], z[4 * c + 3]);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            double e = (double)z[j] * fc.sigma[j];
+            if (t >= 2) e = fc.b0 * e + fc.b1 * e1[j] + fc.b2 * e2[j];
+            e2[j] = e1[j];
+            e1[j] = e;
+            eps[((size_t)t * NV + j) * K + k] = T(e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rollout
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool nonfinite(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ bool nonfinite(double x) {
+    return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+}
+
+template <class T, class MD>
+__global__ void __launch_bounds__(64)
+rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
+               const double* __restrict__ ref, int K, int H, int reward_type, double gamma, int explicit_act,
+               T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status) {
+    constexpr int NV = MD::NV;
+    constexpr int OD = 2 * NV + 6;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    T q[NV], v[NV];
+    static_for<NV>([&](auto Ic) { q[Ic] = T(st->q[Ic]); v[Ic] = T(st->v[Ic]); });
+    RewardParams<T> rp;
+    rp.type = reward_type;
+    rp.alpha = T(st->alpha);
+    rp.target[0] = T(st->target[0]); rp.target[1] = T(st->target[1]); rp.target[2] = T(st->target[2]);
+    const int t0 = st->timestep, ref_len = st->ref_len;
+    const T gm = T(gamma);
+    T ret = T(0), g = T(1);
+    for (int t = 0; t < H; t++) {
+        T a[NV];
+        static_for<NV>([&](auto Jc) {
+            constexpr int j = Jc;
+            const T e = eps[((size_t)t * NV + j) * K + k];
+            a[j] = explicit_act ? e : T(base[t * NV + j]) + e;
+        });
+        T rr[3] = {T(0), T(0), T(0)};
+        if (ref_len > 0) {
+            int idx = t0 + t + 1;
+            idx = idx < ref_len ? idx : ref_len - 1;
+            rr[0] = T(ref[3 * idx]); rr[1] = T(ref[3 * idx + 1]); rr[2] = T(ref[3 * idx + 2]);
+        }
+        Vec3<T> hand;
+        int ms = 0;
+        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, ms);
+        ret += g * r;
+        g *= gm;
+        if (rew) rew[(size_t)k * H + t] = r;
+        if (obs) {
+            T* o = obs + ((size_t)k * H + t) * OD;
+            static_for<NV>([&](auto Ic) { o[Ic] = q[Ic]; o[NV + Ic] = v[Ic]; });
+            o[2 * NV + 0] = hand.v[0]; o[2 * NV + 1] = hand.v[1]; o[2 * NV + 2] = hand.v[2];
+            o[2 * NV + 3] = rp.target[0]; o[2 * NV + 4] = rp.target[1]; o[2 * NV + 5] = rp.target[2];
+        }
+    }
+    R[k] = ret;
+    if (nonfinite(ret)) atomicOr(status, 1);
+}
+
+// one fp64 env.step of the real environment; io: in [q(nv) v(nv) target(3) act(nv) alpha refrow(3)], out [q v obs(2nv+6) reward]
+template <class MD>
+__global__ void env_step_kernel(const double* __restrict__ in, int reward_type, int has_ref, int forward_only,
+                                double* __restrict__ out) {
+    constexpr int NV = MD::NV;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double q[NV], v[NV], a[NV];
+    static_for<NV>([&](auto Ic) { q[Ic] = in[Ic]; v[Ic] = in[NV + Ic]; a[Ic] = in[2 * NV + 3 + Ic]; });
+    RewardParams<double> rp;
+    rp.type = reward_type;
+    rp.target[0] = in[2 * NV]; rp.target[1] = in[2 * NV + 1]; rp.target[2] = in[2 * NV + 2];
+    rp.alpha = in[3 * NV + 3];
+    const double* rr = in + 3 * NV + 4;
+    Vec3<double> hand;
+    double r = 0.0;
+    if (forward_only) {
+        // sim.forward(): kinematics only; the substep leaves q, v untouched copies
+        double q2[NV], v2[NV], z[NV];
+        static_for<NV>([&](auto Ic) { q2[Ic] = q[Ic]; v2[Ic] = v[Ic]; z[Ic] = 0.0; });
+        typename Step<double, MD>::Out o;
+        int sw;
+        Step<double, MD>::substep(q2, v2, z, o, sw);
+        hand = o.hand;
+    } else {
+        int ms = 0;
+        r = Env<double, MD>::step(q, v, a, rp, has_ref ? rr : nullptr, hand, ms);
+    }
+    static_for<NV>([&](auto Ic) { out[Ic] = q[Ic]; out[NV + Ic] = v[Ic]; out[2 * NV + Ic] = q[Ic]; out[3 * NV + Ic] = v[Ic]; });
+    out[4 * NV + 0] = hand.v[0]; out[4 * NV + 1] = hand.v[1]; out[4 * NV + 2] = hand.v[2];
+    out[4 * NV + 3] = rp.target[0]; out[4 * NV + 4] = rp.target[1]; out[4 * NV + 5] = rp.target[2];
+    out[4 * NV + 6] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// update kernels (fp64 accumulation, fixed reduction order -> bitwise reproducible)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void argmax_combine(double& v, int& i, double ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ double shfl_xor_d(double x, int m) { return __shfl_xor(x, m, 64); }
+
+// single block: Rmax / first arg-max over K, S[k], sum S  -> part[0..2]
+template <class T>
+__global__ void __launch_bounds__(1024) weights_kernel(const T* __restrict__ R, int K, double kappa, int k_offset,
+                                                       double* __restrict__ S, double* __restrict__ part) {
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    __shared__ double s_bcast;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double bv = -DBL_MAX;
+    int bi = INT_MAX;
+    for (int k = tid; k < K; k += 1024) argmax_combine(bv, bi, (double)R[k], k);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = shfl_xor_d(bv, m);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    __syncthreads();
+    bv = s_v[0]; bi = s_i[0];
+    for (int w = 1; w < 16; w++) argmax_combine(bv, bi, s_v[w], s_i[w]);
+    __syncthreads();
+    double den = 0.0;
+    for (int k = tid; k < K; k += 1024) {
+        const double s = exp(kappa * ((double)R[k] - bv));
+        S[k] = s;
+        den += s;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) den += shfl_xor_d(den, m);
+    if (lane == 0) s_v[wave] = den;
+    __syncthreads();
+    if (tid == 0) {
+        double d = 0.0;
+        for (int w = 0; w < 16; w++) d += s_v[w];
+        part[0] = bv;
+        part[1] = (double)(k_offset + bi);
+        part[2] = d;
+    }
+}
+
+// block hm: num[hm] = sum_k S[k] * eps[hm][k]
+template <class T>
+__global__ void __launch_bounds__(256) wsum_kernel(const double* __restrict__ S, const T* __restrict__ eps, int K,
+                                                   double* __restrict__ part) {
+    __shared__ double s_v[4];
+    const int hm = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* e = eps + (size_t)hm * K;
+    double num = 0.0;
+    for (int k = tid; k < K; k += 256) num += S[k] * (double)e[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) num += shfl_xor_d(num, m);
+    if (lane == 0) s_v[wave] = num;
+    __syncthreads();
+    if (tid == 0) part[3 + hm] = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
+}
+
+// act_sequence = sum_k S_k (base + eps_k) / (sum S + 1e-6) from nranks shard statistics, rank order
+__global__ void merge_kernel(const double* __restrict__ gathered, int nranks, int HM, double kappa,
+                             double* __restrict__ base, double* __restrict__ result) {
+    const int stride = 3 + HM;
+    double gmax = -DBL_MAX, gidx = 0.0;
+    for (int r = 0; r < nranks; r++) {
+        const double m = gathered[(size_t)r * stride];
+        if (m > gmax) { gmax = m; gidx = gathered[(size_t)r * stride + 1]; }
+    }
+    double den = 0.0;
+    for (int r = 0; r < nranks; r++) den += exp(kappa * (gathered[(size_t)r * stride] - gmax)) * gathered[(size_t)r * stride + 2];
+    for (int hm = blockIdx.x * blockDim.x + threadIdx.x; hm < HM; hm += gridDim.x * blockDim.x) {
+        double num = 0.0;
+        for (int r = 0; r < nranks; r++)
+            num += exp(kappa * (gathered[(size_t)r * stride] - gmax)) * gathered[(size_t)r * stride + 3 + hm];
+        base[hm] = (base[hm] * den + num) / (den + 1e-6);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { result[0] = gmax; result[1] = gidx; }
+}
+
+// tmp[t] = src[t+1], tail = previous last row (repeat) or mean
+__global__ void shift_kernel(const double* __restrict__ src, int H, int M, int tail_mode, const double* __restrict__ mean,
+                             double* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * M; i += gridDim.x * blockDim.x) {
+        const int t = i / M, j = i - t * M;
+        double v;
+        if (t < H - 1) v = src[(t + 1) * M + j];
+        else v = (tail_mode == MPPI_TAIL_REPEAT) ? src[(H - 1) * M + j] : mean[j];
+        dst[i] = v;
+    }
+}
+
+// `MPPI.update` for caller-supplied (actions, returns): block hm
+__global__ void __launch_bounds__(256) update_direct_kernel(const double* __restrict__ act, const double* __restrict__ R,
+                                                            int K, int HM, double kappa, double* __restrict__ out) {
+    __shared__ double s_v[4];
+    const int hm = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double bv = -DBL_MAX;
+    for (int k = tid; k < K; k += 256) bv = R[k] > bv ? R[k] : bv;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const double o = shfl_xor_d(bv, m); bv = o > bv ? o : bv; }
+    if (lane == 0) s_v[wave] = bv;
+    __syncthreads();
+    bv = s_v[0];
+    for (int w = 1; w < 4; w++) bv = s_v[w] > bv ? s_v[w] : bv;
+    __syncthreads();
+    double num = 0.0, den = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const double s = exp(kappa * (R[k] - bv));
+        num += s * act[(size_t)k * HM + hm];
+        den += s;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { num += shfl_xor_d(num, m); den += shfl_xor_d(den, m); }
+    if (lane == 0) s_v[wave] = num;
+    __syncthreads();
+    const double n = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
+    __syncthreads();
+    if (lane == 0) s_v[wave] = den;
+    __syncthreads();
+    if (tid == 0) out[hm] = n / ((((s_v[0] + s_v[1]) + s_v[2]) + s_v[3]) + 1e-6);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-model dispatch
+// ------------------------------------------------------------------------------------------
+struct RolloutArgs {
+    const DevState* st; const double* base; const void* eps; const double* ref;
+    int K, H, reward_type; double gamma; int explicit_act;
+    void* R; void* obs; void* rew; int* status;
+};
+
+struct ModelOps {
+    const char* name;
+    int nv;
+    bool (*matches)(const mppi_model_desc*, std::string&);
+    hipError_t (*rollout)(int dtype, const RolloutArgs&, hipStream_t);
+    hipError_t (*noise_upload)(int dtype, const double* raw, int K, int H, const FilterCoefs&, int filter, void* eps, hipStream_t);
+    hipError_t (*noise_philox)(int dtype, int K, int H, int k_offset, uint64_t seed, const FilterCoefs&, void* eps, hipStream_t);
+    hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
+};
+
+static bool near(double a, double b) { return std::fabs(a - b) <= 1e-12 * (1.0 + std::fabs(b)); }
+
+template <class MD> static bool model_matches(const mppi_model_desc* d, std::string& why) {
+    constexpr int NV = MD::NV;
+#define CHK(cond, what)                                                                     \
+    if (!(cond)) { why = std::string("model field differs from the compiled kernel: ") + what; return false; }
+    CHK(d->nv == NV, "nv");
+    CHK(d->frame_skip == MD::FRAME_SKIP, "frame_skip");
+    CHK(near(d->h, MD::H), "timestep");
+    CHK(d->contact_link == MD::contact_link, "contact_link");
+    CHK(d->hand_link == MD::hand_link, "hand_link");
+    for (int i = 0; i < NV; i++) {
+        CHK(d->parent[i] == MD::parent[i], "parent");
+        CHK((d->limited[i] != 0) == (MD::limited[i] != 0), "limited");
+        const double m = d->mass[i];
+        for (int c = 0; c < 3; c++) {
+            CHK(near(d->pos[i][c], MD::pos[i][c]), "pos");
+            CHK(near(d->axis[i][c], (c == MD::axis_id[i]) ? (double)MD::axis_sign[i] : 0.0), "axis");
+            CHK(near(m * d->com[i][c], MD::mc[i][c]), "com");
+        }
+        // rotational inertia about the link origin
+        const double* I = d->inertia[i];
+        const double* c = d->com[i];
+        const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+        const double IO[6] = {I[0] + m * (cc - c[0] * c[0]), I[1] + m * (cc - c[1] * c[1]), I[2] + m * (cc - c[2] * c[2]),
+                              I[3] - m * c[0] * c[1],        I[4] - m * c[0] * c[2],        I[5] - m * c[1] * c[2]};
+        for (int e = 0; e < 6; e++) CHK(near(IO[e], MD::IO[i][e]), "inertia");
+        CHK(near(m, MD::mass[i]), "mass");
+        CHK(near(d->armature[i], MD::armature[i]), "armature");
+        CHK(near(d->damping[i], MD::damping[i]), "damping");
+        CHK(near(d->gear[i], MD::gear[i]), "gear");
+        CHK(near(d->ctrl_lo[i], MD::ctrl_lo[i]) && near(d->ctrl_hi[i], MD::ctrl_hi[i]), "ctrlrange");
+        if (MD::limited[i]) {
+            CHK(near(d->range_lo[i], MD::range_lo[i]) && near(d->range_hi[i], MD::range_hi[i]), "range");
+            CHK(near(d->dof_invweight[i], MD::dof_invweight[i]), "dof_invweight");
+        }
+    }
+    if (MD::contact_link >= 0) {
+        for (int c = 0; c < 3; c++) CHK(near(d->contact_pos[c], MD::contact_pos[c]), "contact_pos");
+        CHK(near(d->contact_radius, MD::contact_radius), "contact_radius");
+        CHK(near(d->contact_plane_z, MD::contact_plane_z), "contact_plane_z");
+        CHK(near(d->contact_margin, MD::contact_margin), "contact_margin");
+        CHK(near(d->contact_invweight, MD::contact_invweight), "contact_invweight");
+    }
+    for (int c = 0; c < 3; c++) CHK(near(d->hand_pos[c], MD::hand_pos[c]), "hand_pos");
+    CHK(near(d->solref_k, MD::solref_k) && near(d->solref_b, MD::solref_b), "solref");
+    for (int c = 0; c < 5; c++) CHK(near(d->solimp[c], MD::solimp[c]), "solimp");
+#undef CHK
+    return true;
+}
+
+template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArgs& a, hipStream_t s) {
+    const dim3 grid((a.K + 63) / 64), block(64);
+    if (dtype == MPPI_F32)
+        hipLaunchKernelGGL((rollout_kernel<float, MD>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status);
+    else
+        hipLaunchKernelGGL((rollout_kernel<double, MD>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status);
+    return hipGetLastError();
+}
+template <class MD>
+static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H, const FilterCoefs& fc, int filter, void* eps,
+                                      hipStream_t s) {
+    const dim3 grid((K + 63) / 64), block(64);
+    if (dtype == MPPI_F32)
+        hipLaunchKernelGGL((noise_upload_kernel<float, MD::NV>), grid, block, 0, s, raw, K, H, fc, filter, (float*)eps);
+    else
+        hipLaunchKernelGGL((noise_upload_kernel<double, MD::NV>), grid, block, 0, s, raw, K, H, fc, filter, (double*)eps);
+    return hipGetLastError();
+}
+template <class MD>
+static hipError_t launch_noise_philox(int dtype, int K, int H, int k_offset, uint64_t seed, const FilterCoefs& fc, void* eps,
+                                      hipStream_t s) {
+    const dim3 grid((K + 63) / 64), block(64);
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    if (dtype == MPPI_F32)
+        hipLaunchKernelGGL((noise_philox_kernel<float, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, fc, (float*)eps);
+    else
+        hipLaunchKernelGGL((noise_philox_kernel<double, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, fc, (double*)eps);
+    return hipGetLastError();
+}
+template <class MD>
+static hipError_t launch_env_step(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t s) {
+    hipLaunchKernelGGL((env_step_kernel<MD>), dim3(1), dim3(64), 0, s, in, reward_type, has_ref, forward_only, out);
+    return hipGetLastError();
+}
+template <class MD> static ModelOps make_ops() {
+    return {MD::name, MD::NV, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
+            &launch_env_step<MD>};
+}
+static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>()};
+
+// ------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------
+struct mppi_model {
+    const ModelOps* ops;
+    mppi_model_desc desc;
+    // per-device scratch of the single-step entry points (lazily allocated)
+    double* d_io[16];
+};
+
+struct mppi_planner {
+    const mppi_model* model;
+    mppi_planner_cfg cfg;
+    int nv, HM;
+    size_t esz;            // sizeof(T)
+    hipStream_t stream;
+    DevState* d_state;
+    double* d_base;        // [H][M] act_sequence (fp64 master)
+    double* d_base_tmp;
+    double* d_mean;
+    void* d_eps;           // T [H][M][K]
+    double* d_raw;         // staging for host uploads [K][H][M]
+    double* d_ref;
+    int ref_cap;
+    void* d_R;             // T [K]
+    double* d_S;           // [K]
+    double* d_part;        // [3 + HM]
+    double* d_result;      // [2] Rmax, argmax (after merge)
+    void* d_obs;           // T [K][H][2M+6]
+    void* d_rew;           // T [K][H]
+    int* d_status;
+    int explicit_act;
+    FilterCoefs fc;
+    hipGraphExec_t graph;
+    bool graph_valid;
+};
+
+static hipStream_t pick(mppi_planner* p, void* s) { return s ? (hipStream_t)s : p->stream; }
+
+extern "C" {
+
+int mppi_version(void) { return MPPI_ABI_VERSION; }
+const char* mppi_last_error(void) { return g_err.c_str(); }
+
+int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) {
+    if (!desc || !out) return fail(-1, "null argument");
+    std::string why = "unknown model name";
+    for (const ModelOps& o : g_ops) {
+        if (std::strncmp(desc->name, o.name, sizeof(desc->name)) != 0) continue;
+        if (!o.matches(desc, why)) return fail(-3, std::string("model '") + o.name + "': " + why);
+        mppi_model* m = new mppi_model();
+        m->ops = &o;
+        m->desc = *desc;
+        for (auto& x : m->d_io) x = nullptr;
+        *out = m;
+        return 0;
+    }
+    return fail(-3, std::string("no kernel compiled for model '") + std::string(desc->name, strnlen(desc->name, 64)) + "'");
+}
+
+void mppi_model_destroy(mppi_model* m) {
+    if (!m) return;
+    for (int d = 0; d < 16; d++)
+        if (m->d_io[d]) { (void)hipSetDevice(d); (void)hipFree(m->d_io[d]); }
+    delete m;
+}
+
+int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_planner** out) {
+    if (!m || !cfg || !out) return fail(-1, "null argument");
+    if (cfg->K < 1 || cfg->H < 1) return fail(-1, "K and H must be positive");
+    if (cfg->dtype != MPPI_F32 && cfg->dtype != MPPI_F64) return fail(-1, "dtype must be MPPI_F32 or MPPI_F64");
+    HIP_OK(hipSetDevice(cfg->device));
+    mppi_planner* p = new mppi_planner();
+    std::memset(p, 0, sizeof(*p));
+    p->model = m;
+    p->cfg = *cfg;
+    p->nv = m->ops->nv;
+    p->HM = cfg->H * p->nv;
+    p->esz = cfg->dtype == MPPI_F32 ? 4 : 8;
+    const size_t K = cfg->K, HM = p->HM, OD = 2 * p->nv + 6;
+    HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_OK(hipMalloc(&p->d_state, sizeof(DevState)));
+    HIP_OK(hipMemset(p->d_state, 0, sizeof(DevState)));
+    HIP_OK(hipMalloc(&p->d_base, HM * 8));
+    HIP_OK(hipMalloc(&p->d_base_tmp, HM * 8));
+    HIP_OK(hipMalloc(&p->d_mean, MPPI_MAXV * 8));
+    HIP_OK(hipMemcpy(p->d_mean, cfg->mean, MPPI_MAXV * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&p->d_eps, HM * K * p->esz));
+    HIP_OK(hipMemset(p->d_eps, 0, HM * K * p->esz));
+    HIP_OK(hipMalloc(&p->d_raw, HM * K * 8));
+    HIP_OK(hipMalloc(&p->d_R, K * p->esz));
+    HIP_OK(hipMemset(p->d_R, 0, K * p->esz));
+    HIP_OK(hipMalloc(&p->d_S, K * 8));
+    HIP_OK(hipMalloc(&p->d_part, (3 + HM) * 8));
+    HIP_OK(hipMemset(p->d_part, 0, (3 + HM) * 8));
+    HIP_OK(hipMalloc(&p->d_result, 2 * 8));
+    HIP_OK(hipMemset(p->d_result, 0, 2 * 8));
+    HIP_OK(hipMalloc(&p->d_status, 4));
+    HIP_OK(hipMemset(p->d_status, 0, 4));
+    if (cfg->dump) {
+        HIP_OK(hipMalloc(&p->d_obs, K * cfg->H * OD * p->esz));
+        HIP_OK(hipMalloc(&p->d_rew, K * cfg->H * p->esz));
+    }
+    // act_sequence = ones((H, m)) * mean
+    std::vector<double> base(HM);
+    for (int t = 0; t < cfg->H; t++)
+        for (int j = 0; j < p->nv; j++) base[t * p->nv + j] = cfg->mean[j];
+    HIP_OK(hipMemcpy(p->d_base, base.data(), HM * 8, hipMemcpyHostToDevice));
+    for (int j = 0; j < MPPI_MAXV; j++) p->fc.sigma[j] = cfg->sigma[j];
+    p->fc.b0 = cfg->beta[0]; p->fc.b1 = cfg->beta[1]; p->fc.b2 = cfg->beta[2];
+    *out = p;
+    return 0;
+}
+
+void mppi_planner_destroy(mppi_planner* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->cfg.device);
+    (void)hipStreamSynchronize(p->stream);
+    if (p->graph) (void)hipGraphExecDestroy(p->graph);
+    void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
+                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel, const double* target3, int32_t timestep) {
+    if (!p || !qpos || !qvel || !target3) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    // keep alpha / ref_len: fetch-modify-store through a host copy of the small struct
+    DevState s;
+    HIP_OK(hipMemcpyAsync(&s, p->d_state, sizeof(s), hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    for (int i = 0; i < p->nv; i++) { s.q[i] = qpos[i]; s.v[i] = qvel[i]; }
+    for (int c = 0; c < 3; c++) s.target[c] = target3[c];
+    s.timestep = timestep;
+    HIP_OK(hipMemcpyAsync(p->d_state, &s, sizeof(s), hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int mppi_set_base_actions(mppi_planner* p, const double* act) {
+    if (!p || !act) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipMemcpyAsync(p->d_base, act, (size_t)p->HM * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alpha) {
+    if (!p) return fail(-1, "null argument");
+    if (T < 0 || (T > 0 && !ref)) return fail(-1, "bad reference");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    if (T > p->ref_cap) {
+        if (p->d_ref) HIP_OK(hipFree(p->d_ref));
+        HIP_OK(hipMalloc(&p->d_ref, (size_t)T * 3 * 8));
+        p->ref_cap = T;
+        p->graph_valid = false;
+    }
+    if (T > 0) HIP_OK(hipMemcpy(p->d_ref, ref, (size_t)T * 3 * 8, hipMemcpyHostToDevice));
+    DevState s;
+    HIP_OK(hipMemcpy(&s, p->d_state, sizeof(s), hipMemcpyDeviceToHost));
+    s.alpha = alpha;
+    s.ref_len = T;
+    HIP_OK(hipMemcpy(p->d_state, &s, sizeof(s), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_type) {
+    if (!p) return fail(-1, "null argument");
+    if (reward_type < 0 || reward_type > 3) return fail(-1, "bad reward_type");
+    p->cfg.kappa = kappa; p->cfg.gamma = gamma; p->cfg.reward_type = reward_type;
+    p->graph_valid = false;
+    return 0;
+}
+
+int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) {
+    if (!p || !raw) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    hipStream_t s = pick(p, stream);
+    HIP_OK(hipMemcpyAsync(p->d_raw, raw, (size_t)p->HM * p->cfg.K * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->fc, 1, p->d_eps, s));
+    HIP_OK(hipStreamSynchronize(s));     // the host buffer may be reused by the caller
+    p->explicit_act = 0;
+    return 0;
+}
+
+int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream) {
+    if (!p) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->cfg.k_offset, seed, p->fc, p->d_eps,
+                                       pick(p, stream)));
+    p->explicit_act = 0;
+    return 0;
+}
+
+int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) {
+    if (!p || !act) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    hipStream_t s = pick(p, stream);
+    HIP_OK(hipMemcpyAsync(p->d_raw, act, (size_t)p->HM * p->cfg.K * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->fc, 0, p->d_eps, s));
+    HIP_OK(hipStreamSynchronize(s));
+    p->explicit_act = 1;
+    return 0;
+}
+
+static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
+    RolloutArgs a;
+    a.st = p->d_state; a.base = p->d_base; a.eps = p->d_eps; a.ref = p->d_ref;
+    a.K = p->cfg.K; a.H = p->cfg.H; a.reward_type = p->cfg.reward_type; a.gamma = p->cfg.gamma;
+    a.explicit_act = p->explicit_act;
+    a.R = p->d_R; a.obs = p->d_obs; a.rew = p->d_rew; a.status = p->d_status;
+    HIP_OK(p->model->ops->rollout(p->cfg.dtype, a, s));
+    return 0;
+}
+
+static int launch_partials(mppi_planner* p, hipStream_t s) {
+    if (p->cfg.dtype == MPPI_F32) {
+        hipLaunchKernelGGL((weights_kernel<float>), dim3(1), dim3(1024), 0, s, (const float*)p->d_R, p->cfg.K, p->cfg.kappa,
+                           p->cfg.k_offset, p->d_S, p->d_part);
+        hipLaunchKernelGGL((wsum_kernel<float>), dim3(p->HM), dim3(256), 0, s, p->d_S, (const float*)p->d_eps, p->cfg.K, p->d_part);
+    } else {
+        hipLaunchKernelGGL((weights_kernel<double>), dim3(1), dim3(1024), 0, s, (const double*)p->d_R, p->cfg.K, p->cfg.kappa,
+                           p->cfg.k_offset, p->d_S, p->d_part);
+        hipLaunchKernelGGL((wsum_kernel<double>), dim3(p->HM), dim3(256), 0, s, p->d_S, (const double*)p->d_eps, p->cfg.K, p->d_part);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static int launch_merge(mppi_planner* p, const double* gathered, int nranks, hipStream_t s) {
+    hipLaunchKernelGGL(merge_kernel, dim3((p->HM + 255) / 256), dim3(256), 0, s, gathered, nranks, p->HM, p->cfg.kappa,
+                       p->d_base, p->d_result);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mppi_rollout(mppi_planner* p, void* stream) {
+    if (!p) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    return launch_rollout_only(p, pick(p, stream));
+}
+
+int mppi_local_partials(mppi_planner* p, void* stream) {
+    if (!p) return fail(-1, "null argument");
+    if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    hipStream_t s = pick(p, stream);
+    int rc = launch_rollout_only(p, s);
+    if (rc) return rc;
+    return launch_partials(p, s);
+}
+
+int mppi_partials_ptr(mppi_planner* p, void** ptr, size_t* bytes) {
+    if (!p || !ptr || !bytes) return fail(-1, "null argument");
+    *ptr = p->d_part;
+    *bytes = (size_t)(3 + p->HM) * 8;
+    return 0;
+}
+
+int mppi_merge(mppi_planner* p, const void* gathered, int32_t nranks, void* stream) {
+    if (!p || !gathered || nranks < 1) return fail(-1, "bad argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    return launch_merge(p, (const double*)gathered, nranks, pick(p, stream));
+}
+
+static int build_graph(mppi_planner* p) {
+    if (p->graph) { HIP_OK(hipGraphExecDestroy(p->graph)); p->graph = nullptr; }
+    hipGraph_t g;
+    HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+    int rc = launch_rollout_only(p, p->stream);
+    if (!rc) rc = launch_partials(p, p->stream);
+    if (!rc) rc = launch_merge(p, p->d_part, 1, p->stream);
+    hipError_t e = hipStreamEndCapture(p->stream, &g);
+    if (rc) return rc;
+    HIP_OK(e);
+    HIP_OK(hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0));
+    HIP_OK(hipGraphDestroy(g));
+    p->graph_valid = true;
+    return 0;
+}
+
+int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
+    if (!p || niter < 0) return fail(-1, "bad argument");
+    if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    hipStream_t s = pick(p, stream);
+    static const bool use_graph = [] { const char* e = getenv("MPPI_GRAPH"); return !(e && e[0] == '0'); }();
+    if (use_graph && !p->cfg.dump) {
+        if (!p->graph_valid) { int rc = build_graph(p); if (rc) return rc; }
+        for (int i = 0; i < niter; i++) HIP_OK(hipGraphLaunch(p->graph, s));
+        return 0;
+    }
+    for (int i = 0; i < niter; i++) {
+        int rc = launch_rollout_only(p, s);
+        if (!rc) rc = launch_partials(p, s);
+        if (!rc) rc = launch_merge(p, p->d_part, 1, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) {
+    if (!p) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    hipStream_t s = pick(p, stream);
+    if (override_seq) {
+        HIP_OK(hipMemcpyAsync(p->d_base, override_seq, (size_t)p->HM * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(shift_kernel, dim3((p->HM + 255) / 256), dim3(256), 0, s, p->d_base, p->cfg.H, p->nv, p->cfg.default_act,
+                       p->d_mean, p->d_base_tmp);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(p->d_base, p->d_base_tmp, (size_t)p->HM * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int mppi_synchronize(mppi_planner* p) {
+    if (!p) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+static int read_as_double(mppi_planner* p, const void* dsrc, size_t n, double* dst) {
+    if (p->cfg.dtype == MPPI_F64) {
+        HIP_OK(hipMemcpy(dst, dsrc, n * 8, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(n);
+        HIP_OK(hipMemcpy(tmp.data(), dsrc, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) dst[i] = (double)tmp[i];
+    }
+    return 0;
+}
+
+int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) {
+    if (!p || !dst) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    const size_t K = p->cfg.K, H = p->cfg.H, HM = p->HM, OD = 2 * p->nv + 6;
+    auto need = [&](size_t n) { return bytes == n; };
+    switch (what) {
+    case MPPI_READ_RETURNS:
+        if (!need(K * 8)) return fail(-1, "RETURNS needs K doubles");
+        return read_as_double(p, p->d_R, K, (double*)dst);
+    case MPPI_READ_ACT_SEQ:
+        if (!need(HM * 8)) return fail(-1, "ACT_SEQ needs H*M doubles");
+        HIP_OK(hipMemcpy(dst, p->d_base, HM * 8, hipMemcpyDeviceToHost));
+        return 0;
+    case MPPI_READ_ARGMAX: {
+        if (!need(8)) return fail(-1, "ARGMAX needs one int64");
+        double r[2];
+        HIP_OK(hipMemcpy(r, p->d_result, 16, hipMemcpyDeviceToHost));
+        *(int64_t*)dst = (int64_t)r[1];
+        return 0;
+    }
+    case MPPI_READ_RMAX: {
+        if (!need(8)) return fail(-1, "RMAX needs one double");
+        double r[2];
+        HIP_OK(hipMemcpy(r, p->d_result, 16, hipMemcpyDeviceToHost));
+        *(double*)dst = r[0];
+        return 0;
+    }
+    case MPPI_READ_ACTIONS: {
+        if (!need(K * HM * 8)) return fail(-1, "ACTIONS needs K*H*M doubles");
+        std::vector<double> e(HM * K), base(HM);
+        int rc = read_as_double(p, p->d_eps, HM * K, e.data());
+        if (rc) return rc;
+        HIP_OK(hipMemcpy(base.data(), p->d_base, HM * 8, hipMemcpyDeviceToHost));
+        double* o = (double*)dst;
+        for (size_t k = 0; k < K; k++)
+            for (size_t hm = 0; hm < HM; hm++) {
+                // same arithmetic as the kernel: the sum is formed in the rollout dtype
+                const double b = base[hm], x = e[hm * K + k];
+                double a;
+                if (p->explicit_act) a = x;
+                else if (p->cfg.dtype == MPPI_F32) a = (double)((float)b + (float)x);
+                else a = b + x;
+                o[k * HM + hm] = a;
+            }
+        return 0;
+    }
+    case MPPI_READ_NEXT_OBS:
+        if (!p->d_obs) return fail(-4, "planner was created without cfg.dump");
+        if (!need(K * H * OD * 8)) return fail(-1, "NEXT_OBS needs K*H*(2M+6) doubles");
+        return read_as_double(p, p->d_obs, K * H * OD, (double*)dst);
+    case MPPI_READ_REWARDS:
+        if (!p->d_rew) return fail(-4, "planner was created without cfg.dump");
+        if (!need(K * H * 8)) return fail(-1, "REWARDS needs K*H doubles");
+        return read_as_double(p, p->d_rew, K * H, (double*)dst);
+    case MPPI_READ_STATUS:
+        if (!need(4)) return fail(-1, "STATUS needs one int32");
+        HIP_OK(hipMemcpy(dst, p->d_status, 4, hipMemcpyDeviceToHost));
+        return 0;
+    case MPPI_READ_PARTIALS:
+        if (!need((3 + HM) * 8)) return fail(-1, "PARTIALS needs 3+H*M doubles");
+        HIP_OK(hipMemcpy(dst, p->d_part, (3 + HM) * 8, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    return fail(-1, "unknown read selector");
+}
+
+static int env_io(const mppi_model* m, int device, double** io) {
+    if (device < 0 || device >= 16) return fail(-1, "device ordinal out of range");
+    HIP_OK(hipSetDevice(device));
+    mppi_model* mm = const_cast<mppi_model*>(m);
+    if (!mm->d_io[device]) HIP_OK(hipMalloc(&mm->d_io[device], 512 * 8));
+    *io = mm->d_io[device];
+    return 0;
+}
+
+int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const double* qvel, const double* target3,
+                  const double* act, int32_t timestep, int32_t reward_type, const double* ref, int32_t T, double alpha,
+                  double* qpos_out, double* qvel_out, double* obs_out, double* reward_out) {
+    if (!m || !qpos || !qvel || !target3 || !act) return fail(-1, "null argument");
+    if ((reward_type == MPPI_REWARD_TRACKING || reward_type == MPPI_REWARD_COOLING) && (!ref || T < 1))
+        return fail(-1, "tracking / cooling reward needs a reference");
+    const int nv = m->ops->nv;
+    double* io;
+    int rc = env_io(m, device, &io);
+    if (rc) return rc;
+    double in[4 * MPPI_MAXV + 16];
+    for (int i = 0; i < nv; i++) { in[i] = qpos[i]; in[nv + i] = qvel[i]; in[2 * nv + 3 + i] = act[i]; }
+    for (int c = 0; c < 3; c++) in[2 * nv + c] = target3[c];
+    in[3 * nv + 3] = alpha;
+    const int has_ref = ref && T > 0;
+    if (has_ref) {
+        if (timestep + 1 >= T) return fail(-5, "reference index out of range");   // IndexError in the reference
+        for (int c = 0; c < 3; c++) in[3 * nv + 4 + c] = ref[3 * (timestep + 1) + c];
+    }
+    const int n_in = 3 * nv + 7, n_out = 4 * nv + 7;
+    HIP_OK(hipMemcpy(io, in, n_in * 8, hipMemcpyHostToDevice));
+    HIP_OK(m->ops->env_step(io, reward_type, has_ref, 0, io + 256, 0));
+    double out[4 * MPPI_MAXV + 16];
+    HIP_OK(hipMemcpy(out, io + 256, n_out * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nv; i++) {
+        if (qpos_out) qpos_out[i] = out[i];
+        if (qvel_out) qvel_out[i] = out[nv + i];
+    }
+    if (obs_out) for (int i = 0; i < 2 * nv + 6; i++) obs_out[i] = out[2 * nv + i];
+    if (reward_out) *reward_out = out[4 * nv + 6];
+    return 0;
+}
+
+int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, double* hand3_out) {
+    if (!m || !qpos || !hand3_out) return fail(-1, "null argument");
+    const int nv = m->ops->nv;
+    double* io;
+    int rc = env_io(m, device, &io);
+    if (rc) return rc;
+    double in[4 * MPPI_MAXV + 16] = {0};
+    for (int i = 0; i < nv; i++) in[i] = qpos[i];
+    HIP_OK(hipMemcpy(io, in, (3 * nv + 7) * 8, hipMemcpyHostToDevice));
+    HIP_OK(m->ops->env_step(io, 0, 0, 1, io + 256, 0));
+    double out[4 * MPPI_MAXV + 16];
+    HIP_OK(hipMemcpy(out, io + 256, (4 * nv + 7) * 8, hipMemcpyDeviceToHost));
+    for (int c = 0; c < 3; c++) hand3_out[c] = out[4 * nv + c];
+    return 0;
+}
+
+int mppi_update_from_returns(const mppi_model* m, int32_t device, const double* act, const double* R, int32_t K, int32_t H,
+                             double kappa, double* act_seq_out) {
+    if (!m || !act || !R || !act_seq_out || K < 1 || H < 1) return fail(-1, "bad argument");
+    HIP_OK(hipSetDevice(device));
+    const size_t HM = (size_t)H * m->ops->nv;
+    double *d_act = nullptr, *d_R = nullptr, *d_out = nullptr;
+    HIP_OK(hipMalloc(&d_act, (size_t)K * HM * 8));
+    HIP_OK(hipMalloc(&d_R, (size_t)K * 8));
+    HIP_OK(hipMalloc(&d_out, HM * 8));
+    HIP_OK(hipMemcpy(d_act, act, (size_t)K * HM * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_R, R, (size_t)K * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(update_direct_kernel, dim3(HM), dim3(256), 0, 0, d_act, d_R, K, (int)HM, kappa, d_out);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(act_seq_out, d_out, HM * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipFree(d_act)); HIP_OK(hipFree(d_R)); HIP_OK(hipFree(d_out));
+    return 0;
+}
+
+}  // extern "C"

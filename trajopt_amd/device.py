@@ -1,0 +1,192 @@
+"""Thin object wrappers over the C ABI: a model bound to its compiled kernels and a
+device-resident planner."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+from .model import ModelDesc, get_model
+
+
+def default_device():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class DeviceModel:
+    _cache = {}
+
+    def __init__(self, md: ModelDesc):
+        self.md = md
+        self.nv = md.nv
+        self._h = L._vp()
+        self._c = L.desc_to_c(md)
+        L.check(L.lib().mppi_model_create(C.byref(self._c), C.byref(self._h)))
+
+    @classmethod
+    def get(cls, name):
+        if name not in cls._cache:
+            cls._cache[name] = cls(get_model(name))
+        return cls._cache[name]
+
+    def env_step(self, qpos, qvel, target, act, timestep=0, reward_type="dense", reference=None, alpha=1.0,
+                 device=None):
+        """One fp64 `env.step` on the device -> (qpos', qvel', obs[2nv+6], reward)."""
+        nv = self.nv
+        qpos, qvel, target, act = L.f64(qpos), L.f64(qvel), L.f64(target), L.f64(act)
+        assert qpos.shape == (nv,) and qvel.shape == (nv,) and act.shape == (nv,) and target.shape == (3,)
+        ref = None if reference is None else L.f64(reference)
+        q2, v2, obs = np.empty(nv), np.empty(nv), np.empty(2 * nv + 6)
+        r = C.c_double(0.0)
+        rc = L.lib().mppi_env_step(self._h, default_device() if device is None else device, L.ptr(qpos), L.ptr(qvel),
+                                   L.ptr(target), L.ptr(act), int(timestep), L.REWARD_TYPES[reward_type],
+                                   L.ptr(ref), 0 if ref is None else len(ref), float(alpha), L.ptr(q2), L.ptr(v2),
+                                   L.ptr(obs), C.cast(C.byref(r), L._vp))
+        if rc == -5:
+            raise IndexError("index %d is out of bounds for the reference trajectory" % (timestep + 1))
+        L.check(rc)
+        return q2, v2, obs, r.value
+
+    def forward_hand(self, qpos, device=None):
+        """End-effector site position at qpos (what `sim.forward()` leaves in `site_xpos`)."""
+        qpos = L.f64(qpos)
+        hand = np.empty(3)
+        L.check(L.lib().mppi_env_forward(self._h, default_device() if device is None else device, L.ptr(qpos),
+                                         L.ptr(hand)))
+        return hand
+
+    def update_from_returns(self, actions, R, kappa, device=None):
+        actions, R = L.f64(actions), L.f64(R)
+        K, H, M = actions.shape
+        out = np.empty((H, M))
+        L.check(L.lib().mppi_update_from_returns(self._h, default_device() if device is None else device,
+                                                 L.ptr(actions), L.ptr(R), K, H, float(kappa), L.ptr(out)))
+        return out
+
+
+class DevicePlanner:
+    """Device-resident state of one planner (or of one rank's shard of it)."""
+
+    def __init__(self, model: DeviceModel, K, H, kappa=1.0, gamma=1.0, sigma=None, betas=(1.0, 0.0, 0.0),
+                 mean=None, default_act="repeat", reward_type="dense", dtype="f32", device=None, k_offset=0,
+                 dump=False):
+        self.model, self.K, self.H, self.nv = model, int(K), int(H), model.nv
+        self.dtype = dtype
+        cfg = L.PlannerCfgC()
+        cfg.K, cfg.H = self.K, self.H
+        cfg.dtype = L.F32 if dtype == "f32" else L.F64
+        cfg.device = default_device() if device is None else device
+        cfg.reward_type = L.REWARD_TYPES[reward_type]
+        cfg.default_act = L.TAIL[default_act] if default_act in L.TAIL else L.TAIL["mean"]
+        cfg.k_offset, cfg.dump = int(k_offset), int(bool(dump))
+        cfg.kappa, cfg.gamma = float(kappa), float(gamma)
+        sigma = np.ones(self.nv) if sigma is None else np.broadcast_to(np.asarray(sigma, float), (self.nv,))
+        mean = np.zeros(self.nv) if mean is None else np.asarray(mean, float)
+        for j in range(self.nv):
+            cfg.sigma[j], cfg.mean[j] = float(sigma[j]), float(mean[j])
+        for j in range(3):
+            cfg.beta[j] = float(betas[j])
+        self.dump = bool(dump)
+        self._h = L._vp()
+        L.check(L.lib().mppi_planner_create(model._h, C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().mppi_planner_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs ---------------------------------------------------------------------
+    def set_start_state(self, qpos, qvel, target, timestep=0):
+        qpos, qvel, target = L.f64(qpos), L.f64(qvel), L.f64(target)
+        assert qpos.shape == (self.nv,) and qvel.shape == (self.nv,) and target.shape == (3,)
+        L.check(L.lib().mppi_set_start_state(self._h, L.ptr(qpos), L.ptr(qvel), L.ptr(target), int(timestep)))
+
+    def set_base_actions(self, act):
+        act = L.f64(act)
+        assert act.shape == (self.H, self.nv), act.shape
+        L.check(L.lib().mppi_set_base_actions(self._h, L.ptr(act)))
+
+    def set_reference(self, reference, alpha=1.0):
+        ref = None if reference is None else L.f64(reference)
+        assert ref is None or (ref.ndim == 2 and ref.shape[1] == 3)
+        L.check(L.lib().mppi_set_reference(self._h, L.ptr(ref), 0 if ref is None else len(ref), float(alpha)))
+
+    def set_params(self, kappa, gamma, reward_type):
+        L.check(L.lib().mppi_set_params(self._h, float(kappa), float(gamma), L.REWARD_TYPES[reward_type]))
+
+    def upload_noise(self, raw):
+        raw = L.f64(raw)
+        assert raw.shape == (self.K, self.H, self.nv), raw.shape
+        L.check(L.lib().mppi_upload_noise(self._h, L.ptr(raw), None))
+
+    def generate_noise(self, seed):
+        L.check(L.lib().mppi_generate_noise(self._h, int(seed) & (2 ** 64 - 1), None))
+
+    def upload_actions(self, act):
+        act = L.f64(act)
+        assert act.shape == (self.K, self.H, self.nv), act.shape
+        L.check(L.lib().mppi_upload_actions(self._h, L.ptr(act), None))
+
+    # ---- compute --------------------------------------------------------------------
+    def rollout(self):
+        L.check(L.lib().mppi_rollout(self._h, None))
+
+    def iterate(self, niter=1):
+        L.check(L.lib().mppi_iterate(self._h, int(niter), None))
+
+    def local_partials(self):
+        L.check(L.lib().mppi_local_partials(self._h, None))
+
+    def partials_ptr(self):
+        p, n = L._vp(), C.c_size_t()
+        L.check(L.lib().mppi_partials_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def merge(self, gathered_ptr, nranks):
+        L.check(L.lib().mppi_merge(self._h, L._vp(gathered_ptr), int(nranks), None))
+
+    def shift(self, override=None):
+        o = None if override is None else L.f64(override)
+        L.check(L.lib().mppi_shift(self._h, L.ptr(o), None))
+
+    def synchronize(self):
+        L.check(L.lib().mppi_synchronize(self._h))
+
+    # ---- outputs --------------------------------------------------------------------
+    def _read(self, what, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        L.check(L.lib().mppi_read(self._h, what, L.ptr(out), out.nbytes))
+        return out
+
+    def returns(self):
+        return self._read(L.READ_RETURNS, (self.K,))
+
+    def act_sequence(self):
+        return self._read(L.READ_ACT_SEQ, (self.H, self.nv))
+
+    def argmax(self):
+        return int(self._read(L.READ_ARGMAX, (1,), np.int64)[0])
+
+    def rmax(self):
+        return float(self._read(L.READ_RMAX, (1,))[0])
+
+    def actions(self):
+        return self._read(L.READ_ACTIONS, (self.K, self.H, self.nv))
+
+    def next_observations(self):
+        return self._read(L.READ_NEXT_OBS, (self.K, self.H, 2 * self.nv + 6))
+
+    def rewards(self):
+        return self._read(L.READ_REWARDS, (self.K, self.H))
+
+    def status(self):
+        return int(self._read(L.READ_STATUS, (1,), np.int32)[0])
+
+    def partials(self):
+        return self._read(L.READ_PARTIALS, (3 + self.H * self.nv,))

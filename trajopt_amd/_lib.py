@@ -17,7 +17,7 @@ TAIL = {"repeat": 0, "mean": 1}
 (READ_RETURNS, READ_ACT_SEQ, READ_ARGMAX, READ_ACTIONS, READ_NEXT_OBS, READ_REWARDS, READ_STATUS, READ_RMAX,
  READ_PARTIALS) = range(9)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmppi_hip.so")
+LIB_PATH = os.environ.get("MPPI_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmppi_hip.so")
 
 
 class ModelDescC(C.Structure):
@@ -84,6 +84,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MppiError("HIP library %s is missing: build it with `python -c 'import __graft_entry__ as g; "
                             "g.build()'` or `make -C trajopt_amd/csrc`" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime under the same soname as the system one; a
+        # process that ends up with both cannot open the GPU from the second.  Loading torch
+        # first makes this library bind to the runtime torch uses, so tensors, streams and
+        # RCCL buffers are shared with it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(L, name)

@@ -160,8 +160,14 @@ __device__ __forceinline__ bool nonfinite(double x) {
     return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
 }
 
+#ifndef MPPI_F64_BOUNDS
+#define MPPI_F64_BOUNDS 64
+#endif
+template <class T> struct RolloutBounds { static constexpr int value = 64; };
+template <> struct RolloutBounds<double> { static constexpr int value = MPPI_F64_BOUNDS; };
+
 template <class T, class MD>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(RolloutBounds<T>::value)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
                const double* __restrict__ ref, int K, int H, int reward_type, double gamma, int explicit_act,
                T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status) {

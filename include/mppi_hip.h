@@ -159,9 +159,9 @@ int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const
 int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, double* hand3_out);
 
 /* `MPPI.update(paths)` for caller-supplied trajectories (trajopt/algos/mppi.py:56-65):
- * actions (K,H,M), returns R (K) -> act_sequence (H,M), computed on the device. */
-int mppi_update_from_returns(const mppi_model* m, int32_t device, const double* act_KxHxM, const double* R,
-                             int32_t K, int32_t H, double kappa, double* act_seq_out);
+ * actions (K, H*M), returns R (K) -> act_sequence (H*M), computed on the device. */
+int mppi_update_from_returns(int32_t device, const double* act_KxHM, const double* R, int32_t K, int32_t HM,
+                             double kappa, double* act_seq_out);
 
 /* Philox-4x32-10 block function (host), for known-answer tests of the device generator. */
 void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -1,0 +1,183 @@
+"""The reference's Python API on the HIP path: env duck-type, rollout helpers, MPPI.train_step.
+Needs a GPU (`-m gpu`).  The oracle is only the checker."""
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import ref_mppi
+
+pytestmark = pytest.mark.gpu
+FILTER = [np.ones(7), 0.25, 0.8, 0.0]
+
+
+def test_env_duck_type_and_transitions(transitions, oracle_sim):
+    from trajopt.envs.utils import get_environment
+    e = get_environment('reacher_7dof')
+    assert e.env_name == 'reacher_7dof' and e.action_dim == 7 and e.observation_dim == 26
+    assert e.env_timestep == 1                      # the constructor takes one zero-action step
+    ob = e.reset_model(goal=(0.05, 0.0, -0.1))
+    assert e.env_timestep == 0 and ob.shape == (20,)
+    assert np.allclose(ob[14:17], [0.821, -0.6, 0.0], atol=1e-12) and np.allclose(ob[17:], [0.05, 0.0, -0.1])
+    d = transitions
+    for i in range(0, len(d["reward"]), 97):
+        s = dict(qp=d["qp"][i], qv=d["qv"][i], target_pos=d["target"][i], timestep=int(d["timestep"][i]))
+        e.set_env_state(s)
+        assert np.allclose(e.data.site_xpos[e.hand_sid], oracle_sim.fk_hand(d["qp"][i]), atol=1e-13)   # forward()
+        ob, r, done, info = e.step(d["act"][i])
+        assert done is False and e.env_timestep == s["timestep"] + 1
+        assert np.abs(ob[:17] - d["obs_next"][i][:17]).max() < 1e-10
+        st = e.get_env_state()
+        assert np.abs(st["qp"] - d["qp_next"][i]).max() < 1e-10 and np.array_equal(st["target_pos"], d["target"][i])
+        assert info["state"]["timestep"] == s["timestep"] + 1
+        assert e._get_obs(goal_dist=True).shape == (21,)
+    e2 = pickle.loads(pickle.dumps(e))
+    assert e2.env_name == 'reacher_7dof' and e2.env_timestep == 1
+
+
+def test_reward_types(oracle_sim):
+    from trajopt.envs.utils import get_environment
+    rs = np.random.RandomState(0)
+    ref = rs.randn(40, 3) * 0.3
+    s = dict(qp=rs.uniform(-1, 1, 7), qv=rs.randn(7), target_pos=np.array([0.1, 0.0, 0.1]), timestep=7)
+    a = rs.randn(7) * 2
+    for rt, alpha in (("dense", 1.0), ("sparse", 1.0), ("tracking", 1.0), ("cooling", 0.3)):
+        e = get_environment('reacher_7dof', reward_type=rt, reference=ref)
+        e.reset_model(goal=s["target_pos"], alpha=alpha)
+        e.set_env_state(s)
+        _, r, _, _ = e.step(a)
+        want = oracle_sim.env_step(s["qp"], s["qv"], s["target_pos"], a, 7, rt, ref, alpha)[3]
+        assert abs(r - want) < 1e-10, rt
+    e = get_environment('reacher_7dof', reward_type='tracking', reference=ref[:8])
+    e.set_env_state(s)
+    with pytest.raises(IndexError):
+        e.step(a)
+
+
+def test_gather_paths_parallel_schema_and_values(oracle_sim):
+    from trajopt import utils
+    utils.ROLLOUT_DTYPE = "f64"
+    try:
+        H, ppc, ncpu = 12, 5, 3
+        base = np.random.RandomState(3).randn(H, 7) * 0.2
+        s = dict(qp=np.full(7, 0.1), qv=np.zeros(7), target_pos=np.array([0.0, 0.1, 0.0]), timestep=4)
+        paths = utils.gather_paths_parallel('reacher_7dof', s, base, FILTER, 500, None, 'dense', None, 1.0, ppc, ncpu)
+    finally:
+        utils.ROLLOUT_DTYPE = "f32"
+    assert len(paths) == ppc * ncpu
+    assert sorted(paths[0].keys()) == ['actions', 'env_infos', 'next_observations', 'observations', 'rewards', 'states']
+    raw = ref_mppi.all_raw_normals(500, ppc, ncpu, H, 7)
+    act = base + ref_mppi.filter_noise(raw, FILTER)
+    R_o, nobs_o, rew_o = oracle_sim.rollout(s["qp"], s["qv"], s["target_pos"], 4, act, dump=True)
+    for k, p in enumerate(paths):
+        assert np.array_equal(p["actions"], act[k])           # sample order and worker streams
+        assert p["observations"].shape == (H, 20) and p["rewards"].shape == (H,)
+        assert np.abs(np.array(p["next_observations"]) - nobs_o[k]).max() < 1e-10
+        assert np.abs(p["rewards"] - rew_o[k]).max() < 1e-10
+        assert np.abs(p["observations"][1:] - nobs_o[k][:-1]).max() < 1e-10
+        assert np.allclose(p["observations"][0][14:17], oracle_sim.fk_hand(s["qp"]), atol=1e-13)   # fresh at t = 0
+        assert np.array_equal(p["env_infos"]["state"]["timestep"], 4 + np.arange(H))
+        assert p["env_infos"]["state"]["qp"].shape == (H, 7) and len(p["states"]) == H
+        assert p["states"][3]["timestep"] == 7 and np.array_equal(p["states"][3]["qp"], p["observations"][3][:7])
+    # overlapping worker streams: worker 1 is seeded 5 later, its first sample differs from worker 0's
+    assert not np.array_equal(paths[5]["actions"], paths[0]["actions"])
+
+
+def test_do_env_rollout_and_generate_paths(oracle_sim):
+    from trajopt import utils
+    rs = np.random.RandomState(5)
+    s = dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.zeros(3), timestep=0)
+    acts = [rs.randn(6, 7) for _ in range(3)]
+    ref = rs.randn(10, 3)
+    paths = utils.do_env_rollout('reacher_7dof', s, acts, None, 'tracking', ref, 1.0)
+    R_o, nobs_o, rew_o = oracle_sim.rollout(s["qp"], s["qv"], s["target_pos"], 0, np.stack(acts), "tracking", ref, dump=True)
+    for k in range(3):
+        assert np.abs(paths[k]["rewards"] - rew_o[k]).max() < 1e-4 * (1 + np.abs(rew_o[k]).max())
+        assert np.abs(paths[k]["actions"] - acts[k]).max() < 1e-6
+    with pytest.raises(IndexError):
+        utils.do_env_rollout('reacher_7dof', s, acts, None, 'tracking', ref[:6], 1.0)
+    g = utils.generate_paths('reacher_7dof', s, 4, np.zeros((6, 7)), FILTER, 42, None, 'dense', None, 1.0)
+    want = ref_mppi.filter_noise(ref_mppi.raw_normals(42, 4, 6, 7), FILTER)
+    assert np.abs(np.array([p["actions"] for p in g]) - want).max() < 1e-6
+
+
+def _oracle_train_steps(oracle_sim, steps, niter, H, ppc, ncpu, seed, kappa, gamma, goal, mean, default_act):
+    """The reference's train_step loop restated on the oracle (trajopt/algos/mppi.py:125-196)."""
+    q, v, t = np.zeros(7), np.zeros(7), 0
+    seq = np.ones((H, 7)) * mean
+    log = []
+    for _ in range(steps):
+        raw = ref_mppi.all_raw_normals(seed + t, ppc, ncpu, H, 7)
+        eps = ref_mppi.filter_noise(raw, FILTER)
+        for _ in range(niter):
+            R = oracle_sim.rollout(q, v, goal, t, seq + eps, gamma=gamma)
+            seq = ref_mppi.update(seq + eps, R, kappa)
+        q, v, obs, r, _ = oracle_sim.env_step(q, v, goal, seq[0], t)
+        t += 1
+        seq = ref_mppi.shift(seq, default_act, mean)
+        log.append((q.copy(), v.copy(), r, seq.copy()))
+    return log
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_train_step_matches_oracle_loop(oracle_sim, dtype):
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    goal = np.array([0.05, -0.05, 0.1])
+    e = get_environment('reacher_7dof')
+    e.reset_model(seed=3, goal=goal)
+    H, ppc, ncpu, niter, steps = 16, 20, 2, 2, 12
+    ag = MPPI(e, H=H, paths_per_cpu=ppc, num_cpu=ncpu, kappa=25.0, gamma=0.98, mean=np.zeros(7),
+              filter_coefs=FILTER, default_act='mean', seed=11, dtype=dtype)
+    for _ in range(steps):
+        assert ag.train_step(niter=niter, goal=goal) == []
+    log = _oracle_train_steps(oracle_sim, steps, niter, H, ppc, ncpu, 11, 25.0, 0.98, goal, np.zeros(7), 'mean')
+    tol = 1e-7 if dtype == "f64" else 5e-2       # exp(25 dR) amplifies fp32 return error over 24 updates
+    for k in range(steps):
+        assert np.abs(ag.sol_state[k + 1]["qp"] - log[k][0]).max() < tol
+        assert abs(ag.sol_reward[k] - log[k][2]) < tol * 10
+    assert np.abs(ag.act_sequence - log[-1][3]).max() < tol * 20
+    assert len(ag.sol_act) == steps and np.all(np.array(ag.sol_act)[:10] == 0) and np.any(ag.sol_act[11] != 0)
+    assert ag.sol_obs[-1].shape == (21,) and ag.sol_state[-1]["timestep"] == steps
+    ag2 = pickle.loads(pickle.dumps(ag))             # picklable with a live device planner
+    ag2.train_step(niter=1, goal=goal)
+    assert len(ag2.sol_state) == steps + 2
+
+
+def test_update_with_paths_and_critic():
+    import torch
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    from trajopt.models.critic_nets import Critic
+    torch.manual_seed(0)
+    e = get_environment('reacher_7dof')
+    e.reset_model(goal=(0, 0, 0))
+    ag = MPPI(e, H=8, paths_per_cpu=16, kappa=5.0, gamma=0.9, filter_coefs=FILTER, default_act='mean', seed=5)
+    paths = ag.do_rollouts(5)
+    ag.update(paths)
+    R = ref_mppi.score(np.array([p["rewards"] for p in paths]), 0.9)
+    want = ref_mppi.update(np.array([p["actions"] for p in paths]), R, 5.0)
+    assert np.abs(ag.act_sequence - want).max() < 1e-12
+    for dim in (14, 15, 17, 3, 6):
+        critic = Critic(input_dim=dim)
+        before = len(ag.sol_state)
+        ag.train_step(critic=critic, niter=1, dim=dim)
+        assert len(ag.sol_state) == before + 1
+
+
+def test_dense_planning_reaches_the_target():
+    """Behavioural acceptance with the hyper-parameters of the reference's example script
+    (sandbox/examples/reacher_7dof_mppi.py:11-44, dense reward): the stored reference agent
+    collects -274.76 over 100 steps and ends 0.018 m from the target."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    e = get_environment('reacher_7dof')
+    e.reset_model(seed=3, goal=(0, 0, 0), alpha=1.0)
+    ag = MPPI(e, H=16, paths_per_cpu=40, num_cpu=1, kappa=25.0, gamma=1.0, mean=np.zeros(7), filter_coefs=FILTER,
+              default_act='mean', seed=3)
+    for _ in range(100):
+        ag.train_step(niter=5, goal=(0, 0, 0))
+    total = float(np.sum(ag.sol_reward))
+    final = float(ag.sol_obs[-1][-1])
+    assert total > -350.0, total
+    assert final < 0.06, final

@@ -1,0 +1,105 @@
+"""Host-side planner bookkeeping against vectors produced by the reference's own functions
+(CPU only: a toy env stands in for the simulator, no kernel is launched)."""
+import pickle
+
+import numpy as np
+import pytest
+
+from toy_env import ToyEnv
+
+
+@pytest.mark.parametrize("tag,mode", [("a_repeat", "repeat"), ("a_mean", "mean")])
+def test_advance_time_bookkeeping(planner_vectors, tag, mode):
+    from trajopt.algos.mppi import MPPI
+    v = planner_vectors
+    seq = v[tag + "_init"].copy()
+    ag = MPPI(ToyEnv(), H=5, paths_per_cpu=2, mean=np.array([0.1, 0.2, 0.3]), default_act=mode, init_seq=seq)
+    assert ag.act_sequence is seq                       # init_seq is aliased, not copied
+    for k in range(12):
+        ag.advance_time()
+        assert np.array_equal(ag.act_sequence, v[tag + "_seqs"][k])
+    assert ag.act_sequence is seq                       # shifted in place
+    assert np.array_equal(np.array(ag.sol_act), v[tag + "_sol_act"])
+    assert np.all(np.array(ag.sol_act)[:10] == 0) and np.any(np.array(ag.sol_act)[10:] != 0)
+    assert np.array_equal(np.array(ag.sol_reward), v[tag + "_sol_reward"])
+    assert np.array_equal(np.array(ag.sol_obs), v[tag + "_sol_obs"])
+    assert np.array_equal(np.array([s["x"] for s in ag.sol_state]), v[tag + "_sol_x"])
+
+
+def test_advance_time_with_explicit_sequence():
+    from trajopt.algos.mppi import MPPI
+    ag = MPPI(ToyEnv(), H=4, paths_per_cpu=2, default_act='repeat')
+    other = np.arange(12.0).reshape(4, 3)
+    ag.advance_time(act_sequence=other)
+    assert np.array_equal(ag.act_sequence, np.vstack([other[1:], other[-1:]]))
+
+
+def test_defaults_and_pickle_roundtrip():
+    from trajopt.algos.mppi import MPPI
+    ag = MPPI(ToyEnv(), H=3, paths_per_cpu=4)
+    assert np.array_equal(ag.mean, np.zeros(3)) and ag.filter_coefs[1:] == [1.0, 0.0, 0.0]
+    assert np.array_equal(ag.act_sequence, np.zeros((3, 3)))
+    assert len(ag.sol_state) == 1 and ag.sol_obs[0].shape == (5,)      # obs + goal_dist
+    ag.advance_time()
+    ag2 = pickle.loads(pickle.dumps(ag))
+    assert np.array_equal(ag2.act_sequence, ag.act_sequence) and len(ag2.sol_state) == 2
+    assert ag2._planner is None
+
+
+def test_score_trajectory_and_helpers(planner_vectors):
+    from trajopt.algos.mppi import MPPI
+    from trajopt import utils, tensor_utils
+    v = planner_vectors
+    paths = [dict(actions=v["u_actions"][i], rewards=v["u_rewards"][i], critic_rewards=v["u_critic_rewards"][i])
+             for i in range(len(v["u_rewards"]))]
+    for tag in ("u0", "u1"):
+        kappa, gamma = v[tag + "_kg"]
+        ag = MPPI(ToyEnv(), H=6, paths_per_cpu=12, kappa=kappa, gamma=gamma)
+        assert np.array_equal(ag.score_trajectory(paths), v[tag + "_scores"])
+        assert np.array_equal(ag.score_trajectory(paths, use_critic=True), v[tag + "_scores_critic"])
+        assert np.array_equal(utils.score_trajectory(paths, gamma), v[tag + "_scores"])
+    assert np.array_equal(utils.discount_sum(v["ds_in"], 0.9, 0.5), v["ds_out"])
+    st = tensor_utils.stack_tensor_dict_list([dict(a=np.arange(3) + i, b=dict(c=float(i), d=np.ones((2, 2)) * i))
+                                              for i in range(4)])
+    assert np.array_equal(st["a"], v["st_a"]) and np.array_equal(st["b"]["c"], v["st_bc"])
+    assert np.array_equal(st["b"]["d"], v["st_bd"])
+
+
+@pytest.mark.parametrize("tag", ["p0", "p1", "p2", "p3", "p4"])
+def test_generate_perturbed_actions_and_worker_streams(planner_vectors, tag):
+    from trajopt import utils
+    v = planner_vectors
+    seed, H, m, N = (int(x) for x in v[tag + "_cfg"])
+    fc = [v[tag + "_sigma"], *v[tag + "_betas"]]
+    np.random.seed(seed)
+    got = np.array([utils.generate_perturbed_actions(v[tag + "_base"], fc) for _ in range(N)])
+    assert np.array_equal(got, v[tag + "_acts"])
+    # the raw draws uploaded to the device are the same stream
+    raw = utils.worker_normals(seed, N, H, m)
+    e = raw * fc[0]
+    for t in range(2, H):
+        e[:, t] = fc[1] * e[:, t] + fc[2] * e[:, t - 1] + fc[3] * e[:, t - 2]
+    assert np.array_equal(v[tag + "_base"] + e, v[tag + "_acts"])
+
+
+def test_replay_buffer():
+    from trajopt.utils import ReplayBuffer, Tuple
+    rb = ReplayBuffer(max_size=3)
+    for i in range(5):
+        rb.append(Tuple(i, i, i, i + 1))
+    assert [t.state for t in rb.buffer] == [2, 3, 4]
+    rb.concatenate([Tuple(9, 9, 9, 9)])
+    assert [t.state for t in rb.buffer] == [3, 4, 9]
+    rb.append_dict(dict(states=[0, 1, 2], actions=[0, 1, 2], rewards=[0, 1, 2]))
+    assert len(rb.buffer) == 3 and len(rb.get_minibatch(2)) == 2
+    with pytest.raises(AssertionError):
+        rb.append((1, 2, 3, 4))
+
+
+def test_unknown_env_and_missing_kernel():
+    from trajopt.envs.utils import get_environment
+    from trajopt.algos.mppi import MPPI
+    assert get_environment("hopper_not_here") is None
+    ag = MPPI(ToyEnv(), H=3, paths_per_cpu=4)
+    with pytest.raises(ValueError):
+        ag.train_step()          # no compiled rollout kernel for the toy env: fails loudly, no CPU fallback

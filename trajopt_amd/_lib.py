@@ -71,7 +71,7 @@ _PROTOS = {
     "mppi_synchronize": (C.c_int, [_vp]),
     "mppi_env_step": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _d, _vp, _vp, _vp, _vp]),
     "mppi_env_forward": (C.c_int, [_vp, _i32, _vp, _vp]),
-    "mppi_update_from_returns": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _d, _vp]),
+    "mppi_update_from_returns": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _d, _vp]),
     "mppi_philox4x32": (None, [_vp, _vp, _vp]),
 }
 EXPORTS = tuple(_PROTOS)

@@ -1,0 +1,180 @@
+"""`MPPI` with the reference's constructor, methods and attributes
+(trajopt/algos/mppi.py:15-196), planning on the GPU.
+
+`train_step` keeps the whole iteration on the device: the K perturbed rollouts, their
+discounted returns, the exponentiated-return weights and the weighted action update run as
+kernels behind `mppi_iterate`; only the (H, m) `act_sequence` comes back.  The quirks that
+callers observe are kept: every iteration of one `train_step` sees the same noise
+(seed + t), worker streams overlap (seed + i*paths_per_cpu), the denominator carries 1e-6,
+`sol_act` logs zeros for the first ten steps, `update` rebinds `act_sequence` while
+`advance_time` shifts it in place.
+
+Two keyword arguments are additions with behaviour-preserving defaults:
+    noise  'host'   draw the reference's exact numpy stream on the host and upload it
+           'philox' generate on the device (same distribution, different stream)
+    dtype  'f32' | 'f64' arithmetic of the batched rollouts
+"""
+import numpy as np
+
+from ..device import DeviceModel, DevicePlanner, update_from_returns
+from ..utils import ReplayBuffer, Tuple, all_worker_normals, gather_paths_parallel, score_trajectory  # noqa: F401
+from .trajopt_base import Trajectory
+
+_KERNEL_ENVS = {'reacher_7dof': 'reacher_7dof', 'continual_reacher_7dof': 'reacher_7dof'}
+
+
+class MPPI(Trajectory):
+    def __init__(self, env, H, paths_per_cpu,
+                 num_cpu=1,
+                 kappa=1.0,
+                 gamma=1.0,
+                 mean=None,
+                 filter_coefs=None,
+                 default_act='repeat',
+                 seed=123,
+                 init_seq=None,
+                 reward_type='dense',
+                 reference=None,
+                 noise='host',
+                 dtype='f32'):
+        # like the reference, the base constructor is not run: the env is not reset here
+        self.env, self.seed = env, seed
+        self.n, self.m = env.observation_dim, env.action_dim
+        self.H, self.paths_per_cpu, self.num_cpu = H, paths_per_cpu, num_cpu
+        self.kappa, self.gamma = kappa, gamma
+        self.mean = np.zeros(self.m) if mean is None else mean
+        self.filter_coefs = [np.ones(self.m), 1.0, 0.0, 0.0] if filter_coefs is None else filter_coefs
+        self.default_act = default_act
+
+        self.sol_state = [self.env.get_env_state().copy()]
+        self.sol_act = []
+        self.sol_reward = []
+        self.sol_obs = [self.env._get_obs(goal_dist=True)]
+        self.act_sequence = np.ones((self.H, self.m)) * self.mean
+        if init_seq is not None and init_seq.shape == self.act_sequence.shape:
+            self.act_sequence = init_seq            # aliased on purpose, as in the reference
+
+        self.reward_type = reward_type
+        self.reference = reference
+        self.noise = noise
+        self.dtype = dtype
+        self._planner = None
+        self._planner_key = None
+
+    # ---- pickling: device handles are dropped and rebuilt on demand -------------------------
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop('_planner', None)
+        d.pop('_planner_key', None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.__dict__.setdefault('noise', 'host')
+        self.__dict__.setdefault('dtype', 'f32')
+        self._planner = None
+        self._planner_key = None
+
+    # ---- device planner -----------------------------------------------------------------
+    def _device_planner(self):
+        sigma, b0, b1, b2 = self.filter_coefs
+        sig = tuple(np.broadcast_to(np.asarray(sigma, dtype=np.float64), (self.m,)))
+        key = (self.env.env_name, self.H, self.paths_per_cpu, self.num_cpu, sig, b0, b1, b2, self.dtype,
+               tuple(np.asarray(self.mean, float)), self.default_act)
+        if self._planner is None or key != self._planner_key:
+            if self._planner is not None:
+                self._planner.close()
+            model = DeviceModel.get(_KERNEL_ENVS[self.env.env_name])
+            self._planner = DevicePlanner(model, self.paths_per_cpu * self.num_cpu, self.H, kappa=self.kappa,
+                                          gamma=self.gamma, sigma=sig, betas=(b0, b1, b2), mean=self.mean,
+                                          default_act=self.default_act, dtype=self.dtype)
+            self._planner_key = key
+        rt = self.reward_type if self.reward_type in ('sparse', 'tracking', 'cooling') else 'dense'
+        self._planner.set_params(self.kappa, self.gamma, rt)
+        return self._planner
+
+    # ---- reference API ------------------------------------------------------------------
+    def update(self, paths, use_critic=False):
+        """Weighted action update from caller-supplied paths (trajopt/algos/mppi.py:56-65)."""
+        act = np.array([p["actions"] for p in paths], dtype=np.float64)
+        R = self.score_trajectory(paths, use_critic=use_critic)
+        self.act_sequence = update_from_returns(act, R, self.kappa)
+
+    def advance_time(self, act_sequence=None):
+        """Apply the first action to the real env, log, shift the horizon
+        (trajopt/algos/mppi.py:67-89)."""
+        seq = self.act_sequence if act_sequence is None else act_sequence
+        first = seq[0]
+        self.sol_act.append(np.zeros_like(first) if len(self.sol_act) < 10 else first.copy())
+        self.env.set_env_state(self.sol_state[-1].copy())
+        _, r, _, _ = self.env.step(first)
+        self.sol_state.append(self.env.get_env_state().copy())
+        self.sol_obs.append(self.env._get_obs(goal_dist=True))
+        self.sol_reward.append(r)
+        self.act_sequence[:-1] = seq[1:]
+        self.act_sequence[-1] = self.act_sequence[-2] if self.default_act == 'repeat' else self.mean.copy()
+
+    def score_trajectory(self, paths, use_critic=False):
+        return score_trajectory(paths, self.gamma, use_critic=use_critic)
+
+    def do_rollouts(self, seed, goal=None):
+        return gather_paths_parallel(self.env.env_name, self.sol_state[-1], self.act_sequence, self.filter_coefs,
+                                     seed, goal, self.reward_type, self.reference, self.env.alpha,
+                                     self.paths_per_cpu, self.num_cpu)
+
+    def train_step(self, critic=None, niter=1, act_sequence=None, goal=None, dim=14):
+        t = len(self.sol_state) - 1
+        if critic is None and self.env.env_name in _KERNEL_ENVS:
+            self._plan_on_device(self.seed + t, niter)
+        else:
+            for _ in range(niter):
+                paths = self.do_rollouts(self.seed + t, goal=goal)
+                self._attach_critic_rewards(paths, critic, dim)
+                self.update(paths, use_critic=(critic is not None))
+        self.advance_time(act_sequence=act_sequence)
+        return []
+
+    # ---- device-resident iteration ------------------------------------------------------
+    def _plan_on_device(self, seed, niter):
+        s = self.sol_state[-1]
+        H = self.H
+        tracked = self.reward_type in ('tracking', 'cooling')
+        if tracked:
+            if self.reference is None:
+                raise TypeError("'NoneType' object is not subscriptable")
+            if int(s['timestep']) + H >= len(self.reference):
+                raise IndexError("index %d is out of bounds for axis 0 with size %d"
+                                 % (int(s['timestep']) + H, len(self.reference)))
+        p = self._device_planner()
+        p.set_start_state(s['qp'], s['qv'], s['target_pos'], s['timestep'])
+        p.set_reference(self.reference if tracked else None, self.env.alpha)
+        p.set_base_actions(self.act_sequence)
+        if self.noise == 'philox':
+            p.generate_noise(seed)
+        else:
+            p.upload_noise(all_worker_normals(seed, self.paths_per_cpu, self.num_cpu, H, self.m))
+        p.iterate(niter)
+        self.act_sequence = p.act_sequence()
+
+    def _attach_critic_rewards(self, paths, critic, dim):
+        """Terminal-value inputs by `dim` (trajopt/algos/mppi.py:134-159, 191)."""
+        import torch
+        for path in paths:
+            values = []
+            if critic is not None:
+                obs = torch.tensor(np.asarray(path["next_observations"]), dtype=torch.float32)
+                if dim == 14:
+                    x = obs[:, :14]
+                elif dim == 15:
+                    d = torch.linalg.norm(obs[:, -6:-3] - obs[:, -3:], dim=1, keepdim=True)
+                    x = torch.cat((obs[:, :14], d), dim=1)
+                elif dim == 17:
+                    x = torch.cat((obs[:, :14], obs[:, -3:]), dim=1)
+                elif dim == 3:
+                    x = obs[:, -6:-3]
+                elif dim == 6:
+                    x = obs[:, -6:]
+                else:
+                    raise ValueError("unsupported critic input dim %r" % (dim,))
+                values = critic(x).detach().numpy()
+            path["critic_rewards"] = np.array(values)

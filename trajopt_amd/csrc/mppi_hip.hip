@@ -950,20 +950,19 @@ int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, do
     return 0;
 }
 
-int mppi_update_from_returns(const mppi_model* m, int32_t device, const double* act, const double* R, int32_t K, int32_t H,
-                             double kappa, double* act_seq_out) {
-    if (!m || !act || !R || !act_seq_out || K < 1 || H < 1) return fail(-1, "bad argument");
+int mppi_update_from_returns(int32_t device, const double* act, const double* R, int32_t K, int32_t HM, double kappa,
+                             double* act_seq_out) {
+    if (!act || !R || !act_seq_out || K < 1 || HM < 1) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(device));
-    const size_t HM = (size_t)H * m->ops->nv;
     double *d_act = nullptr, *d_R = nullptr, *d_out = nullptr;
     HIP_OK(hipMalloc(&d_act, (size_t)K * HM * 8));
     HIP_OK(hipMalloc(&d_R, (size_t)K * 8));
-    HIP_OK(hipMalloc(&d_out, HM * 8));
+    HIP_OK(hipMalloc(&d_out, (size_t)HM * 8));
     HIP_OK(hipMemcpy(d_act, act, (size_t)K * HM * 8, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_R, R, (size_t)K * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(update_direct_kernel, dim3(HM), dim3(256), 0, 0, d_act, d_R, K, (int)HM, kappa, d_out);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpy(act_seq_out, d_out, HM * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(act_seq_out, d_out, (size_t)HM * 8, hipMemcpyDeviceToHost));
     HIP_OK(hipFree(d_act)); HIP_OK(hipFree(d_R)); HIP_OK(hipFree(d_out));
     return 0;
 }

@@ -55,13 +55,15 @@ class DeviceModel:
                                          L.ptr(hand)))
         return hand
 
-    def update_from_returns(self, actions, R, kappa, device=None):
-        actions, R = L.f64(actions), L.f64(R)
-        K, H, M = actions.shape
-        out = np.empty((H, M))
-        L.check(L.lib().mppi_update_from_returns(self._h, default_device() if device is None else device,
-                                                 L.ptr(actions), L.ptr(R), K, H, float(kappa), L.ptr(out)))
-        return out
+
+def update_from_returns(actions, R, kappa, device=None):
+    """`MPPI.update` arithmetic on the device for caller-supplied (K,H,M) actions and (K,) returns."""
+    actions, R = L.f64(actions), L.f64(R)
+    K, H, M = actions.shape
+    out = np.empty((H, M))
+    L.check(L.lib().mppi_update_from_returns(default_device() if device is None else device, L.ptr(actions),
+                                             L.ptr(R), K, H * M, float(kappa), L.ptr(out)))
+    return out
 
 
 class DevicePlanner:

@@ -148,6 +148,13 @@ int mppi_merge(mppi_planner* p, const void* gathered_device_ptr, int32_t nranks,
 int mppi_shift(mppi_planner* p, const double* override_seq_HxM, void* stream);
 
 int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);
+
+/* Timing hook (the reference only prints wall-clock around the whole experiment,
+ * sandbox/examples/reacher_7dof_mppi.py:47,61): while enabled, every rollout launch is
+ * bracketed by HIP events on its stream; read returns the summed kernel time and the
+ * number of launches since the last read. */
+int mppi_profile(mppi_planner* p, int32_t enable);
+int mppi_profile_read(mppi_planner* p, double* rollout_ms_total, int32_t* launches);
 int mppi_synchronize(mppi_planner* p);
 
 /* One `env.step(a)` / `sim.forward()` of the real environment in fp64 on the device

@@ -68,6 +68,8 @@ _PROTOS = {
     "mppi_merge": (C.c_int, [_vp, _vp, _i32, _vp]),
     "mppi_shift": (C.c_int, [_vp, _vp, _vp]),
     "mppi_read": (C.c_int, [_vp, _i32, _vp, C.c_size_t]),
+    "mppi_profile": (C.c_int, [_vp, _i32]),
+    "mppi_profile_read": (C.c_int, [_vp, C.POINTER(_d), C.POINTER(_i32)]),
     "mppi_synchronize": (C.c_int, [_vp]),
     "mppi_env_step": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _d, _vp, _vp, _vp, _vp]),
     "mppi_env_forward": (C.c_int, [_vp, _i32, _vp, _vp]),

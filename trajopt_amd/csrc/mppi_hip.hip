@@ -522,6 +522,8 @@ struct mppi_planner {
     FilterCoefs fc;
     hipGraphExec_t graph;
     bool graph_valid;
+    bool profiling;
+    std::vector<hipEvent_t>* prof_events;   // start/stop pairs around every rollout launch
 };
 
 static hipStream_t pick(mppi_planner* p, void* s) { return s ? (hipStream_t)s : p->stream; }
@@ -597,6 +599,7 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     HIP_OK(hipMemcpy(p->d_base, base.data(), HM * 8, hipMemcpyHostToDevice));
     for (int j = 0; j < MPPI_MAXV; j++) p->fc.sigma[j] = cfg->sigma[j];
     p->fc.b0 = cfg->beta[0]; p->fc.b1 = cfg->beta[1]; p->fc.b2 = cfg->beta[2];
+    p->prof_events = new std::vector<hipEvent_t>();
     *out = p;
     return 0;
 }
@@ -605,6 +608,8 @@ void mppi_planner_destroy(mppi_planner* p) {
     if (!p) return;
     (void)hipSetDevice(p->cfg.device);
     (void)hipStreamSynchronize(p->stream);
+    for (hipEvent_t e : *p->prof_events) (void)hipEventDestroy(e);
+    delete p->prof_events;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
                     p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status};
@@ -697,12 +702,23 @@ int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) {
 }
 
 static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (p->profiling) {
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        HIP_OK(hipEventRecord(e0, s));
+    }
     RolloutArgs a;
     a.st = p->d_state; a.base = p->d_base; a.eps = p->d_eps; a.ref = p->d_ref;
     a.K = p->cfg.K; a.H = p->cfg.H; a.reward_type = p->cfg.reward_type; a.gamma = p->cfg.gamma;
     a.explicit_act = p->explicit_act;
     a.R = p->d_R; a.obs = p->d_obs; a.rew = p->d_rew; a.status = p->d_status;
     HIP_OK(p->model->ops->rollout(p->cfg.dtype, a, s));
+    if (p->profiling) {
+        HIP_OK(hipEventRecord(e1, s));
+        p->prof_events->push_back(e0);
+        p->prof_events->push_back(e1);
+    }
     return 0;
 }
 
@@ -778,7 +794,7 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     static const bool use_graph = [] { const char* e = getenv("MPPI_GRAPH"); return !(e && e[0] == '0'); }();
-    if (use_graph && !p->cfg.dump) {
+    if (use_graph && !p->cfg.dump && !p->profiling) {
         if (!p->graph_valid) { int rc = build_graph(p); if (rc) return rc; }
         for (int i = 0; i < niter; i++) HIP_OK(hipGraphLaunch(p->graph, s));
         return 0;
@@ -804,6 +820,32 @@ int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) {
                        p->d_mean, p->d_base_tmp);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(p->d_base, p->d_base_tmp, (size_t)p->HM * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int mppi_profile(mppi_planner* p, int32_t enable) {
+    if (!p) return fail(-1, "null argument");
+    p->profiling = enable != 0;
+    return 0;
+}
+
+int mppi_profile_read(mppi_planner* p, double* rollout_ms_total, int32_t* launches) {
+    if (!p || !rollout_ms_total || !launches) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    double total = 0.0;
+    int n = 0;
+    std::vector<hipEvent_t>& ev = *p->prof_events;
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+        HIP_OK(hipEventSynchronize(ev[i + 1]));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        total += ms;
+        n++;
+    }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+    *rollout_ms_total = total;
+    *launches = n;
     return 0;
 }
 

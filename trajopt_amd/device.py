@@ -89,6 +89,7 @@ class DevicePlanner:
         for j in range(3):
             cfg.beta[j] = float(betas[j])
         self.dump = bool(dump)
+        self._device = int(cfg.device)
         self._h = L._vp()
         L.check(L.lib().mppi_planner_create(model._h, C.byref(cfg), C.byref(self._h)))
 
@@ -127,8 +128,8 @@ class DevicePlanner:
         assert raw.shape == (self.K, self.H, self.nv), raw.shape
         L.check(L.lib().mppi_upload_noise(self._h, L.ptr(raw), None))
 
-    def generate_noise(self, seed):
-        L.check(L.lib().mppi_generate_noise(self._h, int(seed) & (2 ** 64 - 1), None))
+    def generate_noise(self, seed, stream=None):
+        L.check(L.lib().mppi_generate_noise(self._h, int(seed) & (2 ** 64 - 1), stream))
 
     def upload_actions(self, act):
         act = L.f64(act)
@@ -136,26 +137,45 @@ class DevicePlanner:
         L.check(L.lib().mppi_upload_actions(self._h, L.ptr(act), None))
 
     # ---- compute --------------------------------------------------------------------
-    def rollout(self):
-        L.check(L.lib().mppi_rollout(self._h, None))
+    def rollout(self, stream=None):
+        L.check(L.lib().mppi_rollout(self._h, stream))
 
-    def iterate(self, niter=1):
-        L.check(L.lib().mppi_iterate(self._h, int(niter), None))
+    def iterate(self, niter=1, stream=None):
+        L.check(L.lib().mppi_iterate(self._h, int(niter), stream))
 
-    def local_partials(self):
-        L.check(L.lib().mppi_local_partials(self._h, None))
+    def local_partials(self, stream=None):
+        L.check(L.lib().mppi_local_partials(self._h, stream))
+
+    def profile(self, enable=True):
+        L.check(L.lib().mppi_profile(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """(summed rollout-kernel milliseconds, launches) since the last read."""
+        ms, n = C.c_double(), C.c_int32()
+        L.check(L.lib().mppi_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def partials_tensor(self):
+        """torch view (no copy) of this shard's statistics buffer, for collectives."""
+        import torch
+        ptr, nbytes = self.partials_ptr()
+
+        class _View:
+            __cuda_array_interface__ = {"data": (ptr, False), "shape": (nbytes // 8,), "typestr": "<f8",
+                                        "strides": None, "version": 2}
+        return torch.as_tensor(_View(), device="cuda:%d" % self._device)
 
     def partials_ptr(self):
         p, n = L._vp(), C.c_size_t()
         L.check(L.lib().mppi_partials_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def merge(self, gathered_ptr, nranks):
-        L.check(L.lib().mppi_merge(self._h, L._vp(gathered_ptr), int(nranks), None))
+    def merge(self, gathered_ptr, nranks, stream=None):
+        L.check(L.lib().mppi_merge(self._h, L._vp(gathered_ptr), int(nranks), stream))
 
-    def shift(self, override=None):
+    def shift(self, override=None, stream=None):
         o = None if override is None else L.f64(override)
-        L.check(L.lib().mppi_shift(self._h, L.ptr(o), None))
+        L.check(L.lib().mppi_shift(self._h, L.ptr(o), stream))
 
     def synchronize(self):
         L.check(L.lib().mppi_synchronize(self._h))

@@ -17,13 +17,14 @@ static void run(const double* q0, const double* v0, const double* target, const 
     for (int c = 0; c < 3; c++) rp.target[c] = T(target[c]);
     T R = 0, g = 1;
     int ms = 0;
+    unsigned am = ~0u;
     Vec3<T> hand = {{0, 0, 0}};
     for (int t = 0; t < H; t++) {
         T a[NV];
         for (int j = 0; j < NV; j++) a[j] = T(act[t * NV + j]);
         T rr[3] = {0, 0, 0};
         if (ref) for (int c = 0; c < 3; c++) rr[c] = T(ref[3 * (t0 + t + 1) + c]);
-        T r = Env<T, MD>::step(q, v, a, rp, rr, hand, ms);
+        T r = Env<T, MD>::step(q, v, a, rp, rr, hand, am, ms);
         if (rewards) rewards[t] = double(r);
         R += g * r; g *= T(gamma);
     }

@@ -37,7 +37,9 @@ MPPI_HD void static_for(F&& f) {
 }
 
 MPPI_HD void sincos_t(float x, float& s, float& c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MPPI_PRECISE_TRIG)
+    s = __sinf(x); c = __cosf(x);
+#elif defined(__HIP_DEVICE_COMPILE__)
     sincosf(x, &s, &c);
 #else
     s = std::sin(x); c = std::cos(x);
@@ -52,6 +54,24 @@ MPPI_HD void sincos_t(double x, double& s, double& c) {
 }
 MPPI_HD float sqrt_t(float x) { return sqrtf(x); }
 MPPI_HD double sqrt_t(double x) { return sqrt(x); }
+// fp32 on the device uses the hardware reciprocal / reciprocal square root / sine / cosine
+// (about 1 ulp; the angle argument is bounded by the joint ranges); fp64 stays exact
+MPPI_HD float rsqrt_t(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __frsqrt_rn(x);
+#else
+    return 1.0f / std::sqrt(x);
+#endif
+}
+MPPI_HD double rsqrt_t(double x) { return 1.0 / sqrt(x); }
+MPPI_HD float rcp_t(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __frcp_rn(x);
+#else
+    return 1.0f / x;
+#endif
+}
+MPPI_HD double rcp_t(double x) { return 1.0 / x; }
 MPPI_HD float abs_t(float x) { return fabsf(x); }
 MPPI_HD double abs_t(double x) { return fabs(x); }
 
@@ -104,8 +124,33 @@ template <class T, class MD> struct Step {
     template <int I> static MPPI_HD Vec3<T> pos_() { return {{T(MD::pos[I][0]), T(MD::pos[I][1]), T(MD::pos[I][2])}}; }
     template <int I> static MPPI_HD Vec3<T> mc_() { return {{T(MD::mc[I][0]), T(MD::mc[I][1]), T(MD::mc[I][2])}}; }
 
-    // (q, v, ctrl) -> (q', v') in place.  max_sweeps bounds the active-set iteration.
-    static MPPI_HD void substep(T (&q)[NV], T (&qd)[NV], const T (&ctrl)[NV], Out& out, int& sweeps_out) {
+    // true if link a is link l or one of its ancestors
+    static constexpr bool on_path(int a, int l) {
+        while (l >= 0) {
+            if (l == a) return true;
+            l = MD::parent[l];
+        }
+        return false;
+    }
+
+    // coordinates of a point fixed in link I, expressed in every ancestor frame on the way to the
+    // world: x[i] = point in link-i coordinates, returns world coordinates
+    template <int I>
+    static MPPI_HD Vec3<T> point_to_world(const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& x, Vec3<T> (&xs)[NV]) {
+        xs[I] = x;
+        const Vec3<T> xp = add(pos_<I>(), to_parent<MD::axis_id[I]>(cs[I], sn[I], x));
+        if constexpr (MD::parent[I] >= 0) return point_to_world<MD::parent[I]>(cs, sn, xp, xs);
+        else return xp;
+    }
+
+    // (q, v, ctrl) -> (q', v') in place.
+    //   want_hand : also evaluate the end-effector site at the input q
+    //   act_mask  : active constraint rows carried from the previous substep (bit i: limit row
+    //               of joint i, bit NV: contact row); start a rollout with all bits set.  The
+    //               active-set iteration converges to the same unique solution from any start;
+    //               starting from the previous substep's set usually needs a single sweep.
+    static MPPI_HD void substep(T (&q)[NV], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
+                                unsigned& act_mask, int& sweeps_out) {
         T cs[NV], sn[NV];
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
@@ -115,30 +160,12 @@ template <class T, class MD> struct Step {
             sn[i] = (MD::axis_sign[i] > 0) ? s : -s;
         });
 
-        // ---- world kinematics (end-effector site, contact sphere) ----------------------
-        // Rw[i] columns = link axes in world coordinates, pw[i] = link origin in world
-        Vec3<T> Rw[NV][3], pw[NV];
-        static_for<NV>([&](auto Ic) {
-            constexpr int i = Ic;
-            constexpr int p = MD::parent[i];
-            constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
-            Vec3<T> e0, e1, e2, pp;
-            if constexpr (p < 0) {
-                e0 = {{T(1), T(0), T(0)}}; e1 = {{T(0), T(1), T(0)}}; e2 = {{T(0), T(0), T(1)}};
-                pp = {{T(0), T(0), T(0)}};
-            } else {
-                e0 = Rw[p][0]; e1 = Rw[p][1]; e2 = Rw[p][2]; pp = pw[p];
-            }
-            const Vec3<T> E[3] = {e0, e1, e2};
-            pw[i] = add(pp, add(scale(T(MD::pos[i][0]), e0), add(scale(T(MD::pos[i][1]), e1), scale(T(MD::pos[i][2]), e2))));
-            Rw[i][A] = E[A];
-            Rw[i][U] = add(scale(cs[i], E[U]), scale(sn[i], E[W]));
-            Rw[i][W] = add(scale(cs[i], E[W]), scale(-sn[i], E[U]));
-        });
+        // ---- points of interest in world coordinates ----------------------------------------
         if constexpr (MD::hand_link >= 0) {
-            constexpr int L = MD::hand_link;
-            out.hand = add(pw[L], add(scale(T(MD::hand_pos[0]), Rw[L][0]),
-                                      add(scale(T(MD::hand_pos[1]), Rw[L][1]), scale(T(MD::hand_pos[2]), Rw[L][2]))));
+            if (want_hand) {
+                Vec3<T> tmp[NV];
+                out.hand = point_to_world<MD::hand_link>(cs, sn, {{T(MD::hand_pos[0]), T(MD::hand_pos[1]), T(MD::hand_pos[2])}}, tmp);
+            }
         }
 
         // ---- bias forces: recursive Newton-Euler with zero joint acceleration ---------------
@@ -280,21 +307,35 @@ template <class T, class MD> struct Step {
         static_for<NV>([&](auto Ic) { Jc[Ic] = T(0); });
         if constexpr (MD::contact_link >= 0) {
             constexpr int L = MD::contact_link;
-            const Vec3<T> cw = add(pw[L], add(scale(T(MD::contact_pos[0]), Rw[L][0]),
-                                              add(scale(T(MD::contact_pos[1]), Rw[L][1]), scale(T(MD::contact_pos[2]), Rw[L][2]))));
+            Vec3<T> xc[NV];
+            const Vec3<T> cw = point_to_world<L>(cs, sn, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
             const T dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
             if (dist < T(MD::contact_margin)) {
+                // d(z of the sphere centre)/dq_i = z_i . (axis_i x x_i): world z axis and the point, both in link-i coordinates
+                Vec3<T> zl[NV];
                 T vel = T(0);
-                contact_jac<L>(Rw, pw, cw, Jc);
-                static_for<NV>([&](auto Ic) { vel += Jc[Ic] * qd[Ic]; });
+                static_for<NV>([&](auto Ic) {
+                    constexpr int i = Ic;
+                    if constexpr (on_path(i, L)) {
+                        constexpr int p = MD::parent[i];
+                        constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
+                        Vec3<T> zp;
+                        if constexpr (p < 0) zp = {{T(0), T(0), T(1)}};
+                        else zp = zl[p];
+                        zl[i] = to_child<A>(cs[i], sn[i], zp);
+                        // (e_A x x)[U] = -x[W], (e_A x x)[W] = x[U]
+                        Jc[i] = T(MD::axis_sign[i]) * (zl[i].v[W] * xc[i].v[U] - zl[i].v[U] * xc[i].v[W]);
+                        vel += Jc[i] * qd[i];
+                    }
+                });
                 row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), Dc, arc);
                 any_row = true;
             }
         }
 
         if (any_row) {
-            bool actl[NV], actc = Dc > T(0);
-            static_for<NV>([&](auto Ic) { actl[Ic] = Dl[Ic] > T(0); });
+            bool actl[NV], actc = (Dc > T(0)) && ((act_mask >> NV) & 1u);
+            static_for<NV>([&](auto Ic) { actl[Ic] = (Dl[Ic] > T(0)) && ((act_mask >> Ic) & 1u); });
             T acc[NV], resl[NV], resc = T(0);
             for (;;) {
                 sweeps++;
@@ -336,6 +377,13 @@ template <class T, class MD> struct Step {
                     static_for<NV>([&](auto Ic) { fc[Ic] += Jc[Ic] * f; });
                 }
             }
+            // rows that do not exist start active when they next appear
+            unsigned m = 0u;
+            static_for<NV>([&](auto Ic) { m |= ((Dl[Ic] > T(0)) && !actl[Ic]) ? 0u : (1u << Ic); });
+            m |= ((Dc > T(0)) && !actc) ? 0u : (1u << NV);
+            act_mask = m;
+        } else {
+            act_mask = ~0u;
         }
         sweeps_out = sweeps;
 
@@ -370,28 +418,18 @@ template <class T, class MD> struct Step {
 
     // impedance, stiffness/damping reference and regulariser of one constraint row
     static MPPI_HD void row_constants(T x, T vel, T invweight, T& D, T& aref) {
-        const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]), width = T(MD::solimp[2]), mid = T(MD::solimp[3]);
+        const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]), mid = T(MD::solimp[3]);
         static_assert(MD::solimp[4] == 2.0, "impedance power other than 2 is not compiled in");
-        const T u = abs_t(x) / width;
+        const T u = abs_t(x) * T(1.0 / MD::solimp[2]);
         T imp = dmax;
         if (u < T(1)) {
             T y;
-            if (u <= mid) y = u * u / mid;
-            else { const T w = T(1) - u; y = T(1) - w * w / (T(1) - mid); }
+            if (u <= mid) y = u * u * T(1.0 / MD::solimp[3]);
+            else { const T w = T(1) - u; y = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3])); }
             imp = d0 + y * (dmax - d0);
         }
         aref = -T(MD::solref_b) * vel - T(MD::solref_k) * imp * x;
-        D = imp / ((T(1) - imp) * invweight);
-    }
-
-    // d(z of contact sphere centre)/dq for the ancestors of link L
-    template <int L>
-    static MPPI_HD void contact_jac(const Vec3<T> (&Rw)[NV][3], const Vec3<T> (&pw)[NV], const Vec3<T>& cw, T (&Jc)[NV]) {
-        constexpr int A = MD::axis_id[L];
-        const Vec3<T>& a = Rw[L][A];
-        const T rx = cw.v[0] - pw[L].v[0], ry = cw.v[1] - pw[L].v[1];
-        Jc[L] = T(MD::axis_sign[L]) * (a.v[0] * ry - a.v[1] * rx);
-        if constexpr (MD::parent[L] >= 0) contact_jac<MD::parent[L]>(Rw, pw, cw, Jc);
+        D = imp * rcp_t((T(1) - imp) * invweight);
     }
 
     // in-place Cholesky of the lower triangle of A, then solve A x = b (b overwritten)
@@ -401,9 +439,7 @@ template <class T, class MD> struct Step {
             constexpr int j = Jn;
             T s = A[j][j];
             static_for<j>([&](auto Kn) { s -= A[j][Kn] * A[j][Kn]; });
-            const T d = sqrt_t(s);
-            inv[j] = T(1) / d;
-            A[j][j] = d;
+            inv[j] = rsqrt_t(s);
             static_for<NV - 1 - j>([&](auto In) {
                 constexpr int i = j + 1 + In;
                 T t = A[i][j];

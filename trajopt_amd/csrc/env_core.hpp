@@ -19,6 +19,18 @@ template <class T> struct RewardParams {
     T target[3];
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The fp64 substep is kept out of line on the device: inlined into the rollout loop it is
+// miscompiled by ROCm 7.2's hipcc (wrong values that change from build to build); as a
+// function of its own it matches the fp64 oracle to rounding.  fp32 stays inline.
+template <class MD>
+__device__ __noinline__ void substep_outofline(double (&q)[MD::NV], double (&qd)[MD::NV], const double (&act)[MD::NV],
+                                               bool want_hand, typename Step<double, MD>::Out& o, unsigned& act_mask,
+                                               int& sw) {
+    Step<double, MD>::substep(q, qd, act, want_hand, o, act_mask, sw);
+}
+#endif
+
 template <class T, class MD> struct Env {
     static constexpr int NV = MD::NV;
     using S = Step<T, MD>;
@@ -42,11 +54,20 @@ template <class T, class MD> struct Env {
     }
 
     static MPPI_HD T step(T (&q)[NV], T (&qd)[NV], const T (&act)[NV], const RewardParams<T>& rp, const T* ref_row,
-                          Vec3<T>& hand, int& max_sweeps) {
+                          Vec3<T>& hand, unsigned& act_mask, int& max_sweeps) {
         typename S::Out o;
+        o.hand = {{T(0), T(0), T(0)}};
+#if defined(__clang__)
+#pragma nounroll
+#endif
         for (int s = 0; s < MD::FRAME_SKIP; s++) {
             int sw;
-            S::substep(q, qd, act, o, sw);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (std::is_same<T, double>::value) substep_outofline<MD>(q, qd, act, s == MD::FRAME_SKIP - 1, o, act_mask, sw);
+            else S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, act_mask, sw);
+#else
+            S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, act_mask, sw);
+#endif
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
         }
         hand = o.hand;

@@ -184,6 +184,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     const int t0 = st->timestep, ref_len = st->ref_len;
     const T gm = T(gamma);
     T ret = T(0), g = T(1);
+    unsigned act_mask = ~0u;
     for (int t = 0; t < H; t++) {
         T a[NV];
         static_for<NV>([&](auto Jc) {
@@ -199,7 +200,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         }
         Vec3<T> hand;
         int ms = 0;
-        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, ms);
+        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_mask, ms);
         ret += g * r;
         g *= gm;
         if (rew) rew[(size_t)k * H + t] = r;
@@ -235,11 +236,13 @@ __global__ void env_step_kernel(const double* __restrict__ in, int reward_type, 
         static_for<NV>([&](auto Ic) { q2[Ic] = q[Ic]; v2[Ic] = v[Ic]; z[Ic] = 0.0; });
         typename Step<double, MD>::Out o;
         int sw;
-        Step<double, MD>::substep(q2, v2, z, o, sw);
+        unsigned am = ~0u;
+        Step<double, MD>::substep(q2, v2, z, true, o, am, sw);
         hand = o.hand;
     } else {
         int ms = 0;
-        r = Env<double, MD>::step(q, v, a, rp, has_ref ? rr : nullptr, hand, ms);
+        unsigned am = ~0u;
+        r = Env<double, MD>::step(q, v, a, rp, has_ref ? rr : nullptr, hand, am, ms);
     }
     static_for<NV>([&](auto Ic) { out[Ic] = q[Ic]; out[NV + Ic] = v[Ic]; out[2 * NV + Ic] = q[Ic]; out[3 * NV + Ic] = v[Ic]; });
     out[4 * NV + 0] = hand.v[0]; out[4 * NV + 1] = hand.v[1]; out[4 * NV + 2] = hand.v[2];

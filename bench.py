@@ -5,9 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one planning step of `MPPI.train_step(niter=1)` with everything resident on the
-device: Philox noise + filter, K x H rollouts with fused reward / discounted return,
-max / weights / weighted action sum, (N > 1: one RCCL all-gather of the per-rank statistics),
-merge into act_sequence, horizon shift, and the single fp64 step of the real environment.
+device and enqueued on one stream without host synchronisation: Philox noise + filter,
+K x H rollouts with fused reward / discounted return, max / weights / weighted action sum,
+(N > 1: one RCCL all-gather of the per-rank statistics), merge into act_sequence, the single
+fp64 step of the real environment from the planner's own state, and the horizon shift.
 With N ranks each rank rolls out its own K = 4096 shard of a 4096*N-sample planner (weak
 scaling); sample noise is addressed by global index so the result does not depend on N.
 
@@ -117,8 +118,7 @@ def main():
     p = DevicePlanner(dm, K_PER_GPU, H, kappa=KAPPA, gamma=GAMMA, sigma=FILTER[0], betas=FILTER[1:],
                       mean=np.zeros(M), default_act="mean", dtype="f32", device=local_rank,
                       k_offset=rank * K_PER_GPU)
-    goal = np.zeros(3)
-    q, v, tstep = np.zeros(M), np.zeros(M), 0
+    p.set_start_state(np.zeros(M), np.zeros(M), np.zeros(3), 0)
     p.set_base_actions(np.zeros((H, M)))
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
@@ -127,20 +127,15 @@ def main():
         gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
 
     def planning_step():
-        nonlocal q, v, tstep
-        p.set_start_state(q, v, goal, tstep)
-        p.generate_noise(SEED + tstep, sptr)
+        # everything below is enqueued on one stream; there is no host synchronisation inside a step
+        p.generate_noise_step(SEED, sptr)            # Philox key = SEED + current timestep (read on the device)
         if world == 1:
-            p.iterate(1, sptr)
+            p.iterate(1, sptr)                       # rollouts + weights + weighted sum + merge
         else:
             p.local_partials(sptr)
             dist.all_gather_into_tensor(gathered, part)
             p.merge(gathered.data_ptr(), world, sptr)
-        stream.synchronize()
-        seq0 = p.act_sequence()[0]
-        q, v, _, _ = dm.env_step(q, v, goal, seq0, tstep, device=local_rank)     # the real env's step (fp64)
-        tstep += 1
-        p.shift(None, sptr)
+        p.advance(sptr)                              # real env fp64 step with act_sequence[0], log, horizon shift
 
     def barrier():
         if world > 1:
@@ -191,6 +186,9 @@ def main():
         }
         if base is not None:
             out["cpu_baseline"] = base
+        log = p.read_log(args.steps + args.warmup)
+        out["config"]["real_env_steps_logged"] = int(log["total"])
+        out["config"]["final_hand_target_distance"] = float(np.linalg.norm(log["hand"][-1] - log["target"][-1]))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

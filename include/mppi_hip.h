@@ -23,6 +23,7 @@ extern "C" {
 
 #define MPPI_MAXV 32
 #define MPPI_ABI_VERSION 1
+#define MPPI_LOG_CAP 4096
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_REWARD_DENSE = 0, MPPI_REWARD_SPARSE = 1, MPPI_REWARD_TRACKING = 2, MPPI_REWARD_COOLING = 3 };
@@ -125,6 +126,9 @@ int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_
  * generate: counter-based Philox-4x32-10 stream keyed by seed, counter = global sample index. */
 int mppi_upload_noise(mppi_planner* p, const double* raw_KxHxM, void* stream);
 int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream);
+/* Same, with the stream key = seed + the planner's current timestep read on the device: the
+ * reference re-seeds every planning step with `self.seed + t` (trajopt/algos/mppi.py:130-132). */
+int mppi_generate_noise_step(mppi_planner* p, uint64_t seed, void* stream);
 /* `act_list` of `do_env_rollout` (trajopt/utils.py:59): explicit action sequences (K,H,M);
  * the next mppi_rollout uses them verbatim. */
 int mppi_upload_actions(mppi_planner* p, const double* act_KxHxM, void* stream);
@@ -146,6 +150,14 @@ int mppi_merge(mppi_planner* p, const void* gathered_device_ptr, int32_t nranks,
 /* Horizon shift and tail fill of `MPPI.advance_time` (trajopt/algos/mppi.py:85-89);
  * override_seq_HxM may be NULL (use the planner's own sequence). */
 int mppi_shift(mppi_planner* p, const double* override_seq_HxM, void* stream);
+
+/* Device-resident `MPPI.advance_time` (trajopt/algos/mppi.py:67-89): steps the real environment
+ * in fp64 from the planner's own start state with act_sequence[0], stores the new state as the
+ * next start state (timestep + 1), appends a row [qpos', qvel', hand, target, reward, action]
+ * (3M+7 doubles) to a ring of MPPI_LOG_CAP rows, and shifts the horizon.  No host round trip.
+ * mppi_read_log copies the most recent rows (oldest first); total = rows ever written. */
+int mppi_advance(mppi_planner* p, void* stream);
+int mppi_read_log(mppi_planner* p, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
 
 int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);
 

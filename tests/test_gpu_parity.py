@@ -189,3 +189,38 @@ def test_philox_noise_statistics(dev_model):
     s.set_base_actions(np.zeros((H, 7)))
     s.generate_noise(2024)
     assert np.array_equal(s.actions(), z[2048:3072])
+
+
+def test_device_resident_advance_matches_host_driven_loop(dev_model, oracle_sim):
+    """generate_noise_step / iterate / advance with no host round trip equals the same loop driven
+    from the host (explicit seed + t, env_step through the ABI, shift)."""
+    K, H, steps = 128, 8, 5
+    tgt = np.array([0.05, 0.0, 0.05])
+    a = _planner(dev_model, K, H, "f32", gamma=0.97)
+    b = _planner(dev_model, K, H, "f32", gamma=0.97)
+    for p in (a, b):
+        p.set_start_state(np.zeros(7), np.zeros(7), tgt, 3)
+        p.set_base_actions(np.zeros((H, 7)))
+    q, v = np.zeros(7), np.zeros(7)
+    host = []
+    for t in range(steps):
+        a.generate_noise_step(77)
+        a.iterate(2)
+        a.advance()
+        b.set_start_state(q, v, tgt, 3 + t)
+        b.generate_noise(77 + 3 + t)
+        b.iterate(2)
+        seq = b.act_sequence()
+        q, v, obs, r = dev_model.env_step(q, v, tgt, seq[0], 3 + t)
+        host.append((q, v, obs, r, seq[0]))
+        b.shift()
+    log = a.read_log()
+    assert log["total"] == steps and len(log["reward"]) == steps
+    for t in range(steps):
+        assert np.array_equal(log["qpos"][t], host[t][0]) and np.array_equal(log["qvel"][t], host[t][1])
+        assert np.array_equal(log["hand"][t], host[t][2][14:17]) and log["reward"][t] == host[t][3]
+        assert np.array_equal(log["action"][t], host[t][4])
+    assert np.array_equal(a.act_sequence(), b.act_sequence())
+    # and the logged transitions are the oracle's
+    q2, v2, _, r2, _ = oracle_sim.env_step(host[-2][0], host[-2][1], tgt, host[-1][4], 3 + steps - 1)
+    assert np.abs(q2 - log["qpos"][-1]).max() < 1e-10 and abs(r2 - log["reward"][-1]) < 1e-10

@@ -168,109 +168,10 @@ template <class T, class MD> struct Step {
             }
         }
 
-        // ---- bias forces: recursive Newton-Euler with zero joint acceleration ---------------
-        Vec3<T> om[NV], vl[NV], al[NV], ac[NV];       // angular/linear velocity, angular/linear spatial accel
-        Vec3<T> fn[NV], ff[NV];                       // moment about link origin, force
-        static_for<NV>([&](auto Ic) {
-            constexpr int i = Ic;
-            constexpr int p = MD::parent[i];
-            constexpr int A = MD::axis_id[i];
-            const Vec3<T> r = pos_<i>();
-            Vec3<T> w, v, a_w, a_v;
-            if constexpr (p < 0) {
-                w = {{T(0), T(0), T(0)}}; v = w; a_w = w; a_v = w;
-            } else {
-                w = to_child<A>(cs[i], sn[i], om[p]);
-                v = to_child<A>(cs[i], sn[i], add(vl[p], cross(om[p], r)));
-                a_w = to_child<A>(cs[i], sn[i], al[p]);
-                a_v = to_child<A>(cs[i], sn[i], add(ac[p], cross(al[p], r)));
-            }
-            // joint rate about axis A; velocity-product acceleration V x (S qd)
-            Vec3<T> sq = {{T(0), T(0), T(0)}};
-            sq.v[A] = T(MD::axis_sign[i]) * qd[i];
-            a_w = add(a_w, cross(w, sq));
-            a_v = add(a_v, cross(v, sq));
-            w.v[A] += sq.v[A];
-            om[i] = w; vl[i] = v; al[i] = a_w; ac[i] = a_v;
-            const T m = T(MD::mass[i]);
-            const Vec3<T> h = mc_<i>();
-            const T IO[6] = {T(MD::IO[i][0]), T(MD::IO[i][1]), T(MD::IO[i][2]), T(MD::IO[i][3]), T(MD::IO[i][4]), T(MD::IO[i][5])};
-            const Vec3<T> lV = add(scale(m, v), cross(w, h));
-            const Vec3<T> nV = add(sym_mul(IO, w), cross(h, v));
-            const Vec3<T> lA = add(scale(m, a_v), cross(a_w, h));
-            const Vec3<T> nA = add(sym_mul(IO, a_w), cross(h, a_v));
-            fn[i] = add(nA, add(cross(w, nV), cross(v, lV)));
-            ff[i] = add(lA, cross(w, lV));
-        });
         T bias[NV];
-        static_for<NV>([&](auto Ic) {
-            constexpr int i = NV - 1 - Ic;
-            constexpr int p = MD::parent[i];
-            constexpr int A = MD::axis_id[i];
-            bias[i] = T(MD::axis_sign[i]) * fn[i].v[A];
-            if constexpr (p >= 0) {
-                const Vec3<T> r = pos_<i>();
-                const Vec3<T> f = to_parent<A>(cs[i], sn[i], ff[i]);
-                const Vec3<T> n = to_parent<A>(cs[i], sn[i], fn[i]);
-                ff[p] = add(ff[p], f);
-                fn[p] = add(fn[p], add(n, cross(r, f)));
-            }
-        });
-
-        // ---- joint-space inertia: composite rigid bodies in link coordinates ------------------
-        SpInertia<T> Ic_[NV];
-        static_for<NV>([&](auto Ic) {
-            constexpr int i = Ic;
-            Ic_[i].m = T(MD::mass[i]);
-            Ic_[i].h = mc_<i>();
-            static_for<6>([&](auto En) { Ic_[i].I[En] = T(MD::IO[i][En]); });
-        });
+        bias_forces(cs, sn, qd, bias);
         T M[NV][NV];     // lower triangle used: M[i][j], i >= j
-        static_for<NV>([&](auto Icn) {
-            constexpr int i = NV - 1 - Icn;
-            constexpr int p = MD::parent[i];
-            constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
-            // column i of M: force produced by unit acceleration of joint i on composite body i
-            {
-                Vec3<T> ea = {{T(0), T(0), T(0)}};
-                constexpr T sgn = T(MD::axis_sign[i]);
-                ea.v[A] = sgn;
-                Vec3<T> n = {{sgn * Ic_[i].I[sym_idx(0, A)], sgn * Ic_[i].I[sym_idx(1, A)], sgn * Ic_[i].I[sym_idx(2, A)]}};
-                Vec3<T> f = cross(ea, Ic_[i].h);
-                M[i][i] = Ic_[i].I[sym_idx(A, A)] + T(MD::armature[i]);
-                walk_up<i, i>(cs, sn, n, f, M);
-            }
-            if constexpr (p >= 0) {
-                // express composite i in the parent frame and add it to the parent's composite
-                const T c = cs[i], s = sn[i];
-                const T* I = Ic_[i].I;
-                const Vec3<T> h = to_parent<A>(c, s, Ic_[i].h);
-                T J[6];
-                const T cc = c * c, ss = s * s, sc = s * c;
-                const T Iuu = I[sym_idx(U, U)], Iww = I[sym_idx(W, W)], Iuw = I[sym_idx(U, W)];
-                const T Iau = I[sym_idx(A, U)], Iaw = I[sym_idx(A, W)];
-                J[sym_idx(A, A)] = I[sym_idx(A, A)];
-                J[sym_idx(A, U)] = c * Iau - s * Iaw;
-                J[sym_idx(A, W)] = s * Iau + c * Iaw;
-                J[sym_idx(U, U)] = cc * Iuu - T(2) * sc * Iuw + ss * Iww;
-                J[sym_idx(W, W)] = ss * Iuu + T(2) * sc * Iuw + cc * Iww;
-                J[sym_idx(U, W)] = sc * (Iuu - Iww) + (cc - ss) * Iuw;
-                const Vec3<T> r = pos_<i>();
-                const T m = Ic_[i].m;
-                const T rr = r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2];
-                const T rh = r.v[0] * h.v[0] + r.v[1] * h.v[1] + r.v[2] * h.v[2];
-                const T dg = m * rr + T(2) * rh;
-                Ic_[p].m += m;
-                Ic_[p].h = add(Ic_[p].h, add(h, scale(m, r)));
-                static_for<3>([&](auto ax) {
-                    constexpr int a = ax;
-                    Ic_[p].I[sym_idx(a, a)] += J[sym_idx(a, a)] + dg - m * r.v[a] * r.v[a] - T(2) * r.v[a] * h.v[a];
-                });
-                Ic_[p].I[3] += J[3] - m * r.v[0] * r.v[1] - r.v[0] * h.v[1] - h.v[0] * r.v[1];
-                Ic_[p].I[4] += J[4] - m * r.v[0] * r.v[2] - r.v[0] * h.v[2] - h.v[0] * r.v[2];
-                Ic_[p].I[5] += J[5] - m * r.v[1] * r.v[2] - r.v[1] * h.v[2] - h.v[1] * r.v[2];
-            }
-        });
+        mass_matrix(cs, sn, M);
 
         // ---- smooth force -------------------------------------------------------------------
         T fs[NV];
@@ -400,6 +301,114 @@ template <class T, class MD> struct Step {
             qd[i] = qd[i] + T(MD::H) * qacc[i];
             q[i] = q[i] + T(MD::H) * qd[i];
         });
+    }
+
+    // bias forces: recursive Newton-Euler with zero joint acceleration, link-local coordinates
+    static MPPI_HD void bias_forces(const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], T (&bias)[NV]) {
+        Vec3<T> om[NV], vl[NV], al[NV], ac[NV];       // angular/linear velocity, angular/linear spatial accel
+        Vec3<T> fn[NV], ff[NV];                       // moment about link origin, force
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            constexpr int p = MD::parent[i];
+            constexpr int A = MD::axis_id[i];
+            const Vec3<T> r = pos_<i>();
+            Vec3<T> w, v, a_w, a_v;
+            if constexpr (p < 0) {
+                w = {{T(0), T(0), T(0)}}; v = w; a_w = w; a_v = w;
+            } else {
+                w = to_child<A>(cs[i], sn[i], om[p]);
+                v = to_child<A>(cs[i], sn[i], add(vl[p], cross(om[p], r)));
+                a_w = to_child<A>(cs[i], sn[i], al[p]);
+                a_v = to_child<A>(cs[i], sn[i], add(ac[p], cross(al[p], r)));
+            }
+            // joint rate about axis A; velocity-product acceleration V x (S qd)
+            Vec3<T> sq = {{T(0), T(0), T(0)}};
+            sq.v[A] = T(MD::axis_sign[i]) * qd[i];
+            a_w = add(a_w, cross(w, sq));
+            a_v = add(a_v, cross(v, sq));
+            w.v[A] += sq.v[A];
+            om[i] = w; vl[i] = v; al[i] = a_w; ac[i] = a_v;
+            const T m = T(MD::mass[i]);
+            const Vec3<T> h = mc_<i>();
+            const T IO[6] = {T(MD::IO[i][0]), T(MD::IO[i][1]), T(MD::IO[i][2]), T(MD::IO[i][3]), T(MD::IO[i][4]), T(MD::IO[i][5])};
+            const Vec3<T> lV = add(scale(m, v), cross(w, h));
+            const Vec3<T> nV = add(sym_mul(IO, w), cross(h, v));
+            const Vec3<T> lA = add(scale(m, a_v), cross(a_w, h));
+            const Vec3<T> nA = add(sym_mul(IO, a_w), cross(h, a_v));
+            fn[i] = add(nA, add(cross(w, nV), cross(v, lV)));
+            ff[i] = add(lA, cross(w, lV));
+        });
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = NV - 1 - Ic;
+            constexpr int p = MD::parent[i];
+            constexpr int A = MD::axis_id[i];
+            bias[i] = T(MD::axis_sign[i]) * fn[i].v[A];
+            if constexpr (p >= 0) {
+                const Vec3<T> r = pos_<i>();
+                const Vec3<T> f = to_parent<A>(cs[i], sn[i], ff[i]);
+                const Vec3<T> n = to_parent<A>(cs[i], sn[i], fn[i]);
+                ff[p] = add(ff[p], f);
+                fn[p] = add(fn[p], add(n, cross(r, f)));
+            }
+        });
+
+    }
+
+    // joint-space inertia (lower triangle, armature included): composite rigid bodies in link coordinates
+    static MPPI_HD void mass_matrix(const T (&cs)[NV], const T (&sn)[NV], T (&M)[NV][NV]) {
+        SpInertia<T> Ic_[NV];
+        static_for<NV>([&](auto Ic) {
+            constexpr int i = Ic;
+            Ic_[i].m = T(MD::mass[i]);
+            Ic_[i].h = mc_<i>();
+            static_for<6>([&](auto En) { Ic_[i].I[En] = T(MD::IO[i][En]); });
+        });
+        static_for<NV>([&](auto Icn) {
+            constexpr int i = NV - 1 - Icn;
+            constexpr int p = MD::parent[i];
+            constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
+            // column i of M: force produced by unit acceleration of joint i on composite body i
+            {
+                Vec3<T> ea = {{T(0), T(0), T(0)}};
+                constexpr T sgn = T(MD::axis_sign[i]);
+                ea.v[A] = sgn;
+                Vec3<T> n = {{sgn * Ic_[i].I[sym_idx(0, A)], sgn * Ic_[i].I[sym_idx(1, A)], sgn * Ic_[i].I[sym_idx(2, A)]}};
+                Vec3<T> f = cross(ea, Ic_[i].h);
+                M[i][i] = Ic_[i].I[sym_idx(A, A)] + T(MD::armature[i]);
+                walk_up<i, i>(cs, sn, n, f, M);
+            }
+            if constexpr (p >= 0) {
+                // express composite i in the parent frame and add it to the parent's composite
+                const T c = cs[i], s = sn[i];
+                const T* I = Ic_[i].I;
+                const Vec3<T> h = to_parent<A>(c, s, Ic_[i].h);
+                T J[6];
+                const T cc = c * c, ss = s * s, sc = s * c;
+                const T Iuu = I[sym_idx(U, U)], Iww = I[sym_idx(W, W)], Iuw = I[sym_idx(U, W)];
+                const T Iau = I[sym_idx(A, U)], Iaw = I[sym_idx(A, W)];
+                J[sym_idx(A, A)] = I[sym_idx(A, A)];
+                J[sym_idx(A, U)] = c * Iau - s * Iaw;
+                J[sym_idx(A, W)] = s * Iau + c * Iaw;
+                J[sym_idx(U, U)] = cc * Iuu - T(2) * sc * Iuw + ss * Iww;
+                J[sym_idx(W, W)] = ss * Iuu + T(2) * sc * Iuw + cc * Iww;
+                J[sym_idx(U, W)] = sc * (Iuu - Iww) + (cc - ss) * Iuw;
+                const Vec3<T> r = pos_<i>();
+                const T m = Ic_[i].m;
+                const T rr = r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2];
+                const T rh = r.v[0] * h.v[0] + r.v[1] * h.v[1] + r.v[2] * h.v[2];
+                const T dg = m * rr + T(2) * rh;
+                Ic_[p].m += m;
+                Ic_[p].h = add(Ic_[p].h, add(h, scale(m, r)));
+                static_for<3>([&](auto ax) {
+                    constexpr int a = ax;
+                    Ic_[p].I[sym_idx(a, a)] += J[sym_idx(a, a)] + dg - m * r.v[a] * r.v[a] - T(2) * r.v[a] * h.v[a];
+                });
+                Ic_[p].I[3] += J[3] - m * r.v[0] * r.v[1] - r.v[0] * h.v[1] - h.v[0] * r.v[1];
+                Ic_[p].I[4] += J[4] - m * r.v[0] * r.v[2] - r.v[0] * h.v[2] - h.v[0] * r.v[2];
+                Ic_[p].I[5] += J[5] - m * r.v[1] * r.v[2] - r.v[1] * h.v[2] - h.v[1] * r.v[2];
+            }
+        });
+
     }
 
     // carry the force (n about origin of link I, f) of column COL up the tree, filling M[COL][ancestor]

@@ -123,31 +123,39 @@ __global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restri
     }
 }
 
+// one lane per (sample k, action dimension j): counter = (global k, j, block c, 0), block c holds the
+// draws of steps 4c .. 4c+3.  With seed_from_state the stream key is seed + the planner's current
+// timestep (the reference re-seeds every planning step with seed + t, trajopt/algos/mppi.py:130-132)
 template <class T, int NV>
-__global__ void __launch_bounds__(64) noise_philox_kernel(int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
-                                                          FilterCoefs fc, T* __restrict__ eps) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
-    constexpr int CALLS = (NV + 3) / 4;
-    double e1[NV], e2[NV];
+__global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
+                                                           const DevState* __restrict__ st, int seed_from_state,
+                                                           FilterCoefs fc, T* __restrict__ eps) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= K * NV) return;
+    const int j = idx / K, k = idx - j * K;
+    if (seed_from_state) {
+        const uint64_t s = (((uint64_t)seed_hi << 32) | seed_lo) + (uint64_t)(int64_t)st->timestep;
+        seed_lo = (uint32_t)s;
+        seed_hi = (uint32_t)(s >> 32);
+    }
+    const double sigma = fc.sigma[j];
+    double e1 = 0.0, e2 = 0.0;
+    for (int c = 0; 4 * c < H; c++) {
+        uint32_t ctr[4] = {(uint32_t)(k_offset + k), (uint32_t)j, (uint32_t)c, 0u};
+        philox4x32_10(ctr, seed_lo, seed_hi);
+        float z[4];
+        box_muller(ctr[0], ctr[1], z[0], z[1]);
+        box_muller(ctr[2], ctr[3], z[2], z[3]);
 #pragma unroll
-    for (int j = 0; j < NV; j++) e1[j] = e2[j] = 0.0;
-    for (int t = 0; t < H; t++) {
-        float z[CALLS * 4];
-#pragma unroll
-        for (int c = 0; c < CALLS; c++) {
-            uint32_t ctr[4] = {(uint32_t)(k_offset + k), (uint32_t)t, (uint32_t)c, 0u};
-            philox4x32_10(ctr, seed_lo, seed_hi);
-            box_muller(ctr[0], ctr[1], z[4 * c + 0], z[4 * c + 1]);
-            box_muller(ctr[2], ctr[3], z[4 * c + 2], z[4 * c + 3]);
-        }
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            double e = (double)z[j] * fc.sigma[j];
-            if (t >= 2) e = fc.b0 * e + fc.b1 * e1[j] + fc.b2 * e2[j];
-            e2[j] = e1[j];
-            e1[j] = e;
-            eps[((size_t)t * NV + j) * K + k] = T(e);
+        for (int u = 0; u < 4; u++) {
+            const int t = 4 * c + u;
+            if (t < H) {
+                double e = (double)z[u] * sigma;
+                if (t >= 2) e = fc.b0 * e + fc.b1 * e1 + fc.b2 * e2;
+                e2 = e1;
+                e1 = e;
+                eps[((size_t)t * NV + j) * K + k] = T(e);
+            }
         }
     }
 }
@@ -173,7 +181,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
                T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status) {
     constexpr int NV = MD::NV;
     constexpr int OD = 2 * NV + 6;
-    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     T q[NV], v[NV];
     static_for<NV>([&](auto Ic) { q[Ic] = T(st->q[Ic]); v[Ic] = T(st->v[Ic]); });
@@ -248,6 +256,66 @@ __global__ void env_step_kernel(const double* __restrict__ in, int reward_type, 
     out[4 * NV + 0] = hand.v[0]; out[4 * NV + 1] = hand.v[1]; out[4 * NV + 2] = hand.v[2];
     out[4 * NV + 3] = rp.target[0]; out[4 * NV + 4] = rp.target[1]; out[4 * NV + 5] = rp.target[2];
     out[4 * NV + 6] = r;
+}
+
+// Device-resident `advance_time` (trajopt/algos/mppi.py:67-89): lane 0 steps the real environment in fp64 with
+// act_sequence[0] from the planner's own state, appends (q', v', hand, target, reward, action) to the log ring and
+// stores the new state; then the whole block shifts the horizon and fills the tail.
+template <class MD>
+__global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
+                                                      const double* __restrict__ ref, int reward_type, int H, int tail_mode,
+                                                      const double* __restrict__ mean, double* __restrict__ log, int log_cap,
+                                                      int* __restrict__ log_count) {
+    constexpr int NV = MD::NV;
+    constexpr int ROW = 3 * NV + 7;
+    constexpr int PER = 16;                       // H * NV <= 256 * PER
+    const int tid = threadIdx.x;
+    double keep[PER];
+    const int HM = H * NV;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = tid + 256 * u;
+        double v = 0.0;
+        if (i < HM) {
+            const int t = i / NV, j = i - t * NV;
+            if (t < H - 1) v = base[(t + 1) * NV + j];
+            else v = (tail_mode == MPPI_TAIL_REPEAT) ? base[(H - 1) * NV + j] : mean[j];
+        }
+        keep[u] = v;
+    }
+    if (tid == 0) {
+        double q[NV], v[NV], a[NV];
+        static_for<NV>([&](auto Ic) { q[Ic] = st->q[Ic]; v[Ic] = st->v[Ic]; a[Ic] = base[Ic]; });
+        RewardParams<double> rp;
+        rp.type = reward_type;
+        rp.alpha = st->alpha;
+        rp.target[0] = st->target[0]; rp.target[1] = st->target[1]; rp.target[2] = st->target[2];
+        double rr[3] = {0.0, 0.0, 0.0};
+        const int t0 = st->timestep, ref_len = st->ref_len;
+        if (ref_len > 0) {
+            int idx = t0 + 1;
+            idx = idx < ref_len ? idx : ref_len - 1;
+            rr[0] = ref[3 * idx]; rr[1] = ref[3 * idx + 1]; rr[2] = ref[3 * idx + 2];
+        }
+        Vec3<double> hand;
+        int ms = 0;
+        unsigned am = ~0u;
+        const double r = Env<double, MD>::step(q, v, a, rp, rr, hand, am, ms);
+        const int n = *log_count;
+        double* row = log + (size_t)(n % log_cap) * ROW;
+        static_for<NV>([&](auto Ic) { row[Ic] = q[Ic]; row[NV + Ic] = v[Ic]; row[2 * NV + 7 + Ic] = a[Ic]; st->q[Ic] = q[Ic]; st->v[Ic] = v[Ic]; });
+        row[2 * NV + 0] = hand.v[0]; row[2 * NV + 1] = hand.v[1]; row[2 * NV + 2] = hand.v[2];
+        row[2 * NV + 3] = rp.target[0]; row[2 * NV + 4] = rp.target[1]; row[2 * NV + 5] = rp.target[2];
+        row[2 * NV + 6] = r;
+        st->timestep = t0 + 1;
+        *log_count = n + 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = tid + 256 * u;
+        if (i < HM) base[i] = keep[u];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -393,7 +461,10 @@ struct ModelOps {
     bool (*matches)(const mppi_model_desc*, std::string&);
     hipError_t (*rollout)(int dtype, const RolloutArgs&, hipStream_t);
     hipError_t (*noise_upload)(int dtype, const double* raw, int K, int H, const FilterCoefs&, int filter, void* eps, hipStream_t);
-    hipError_t (*noise_philox)(int dtype, int K, int H, int k_offset, uint64_t seed, const FilterCoefs&, void* eps, hipStream_t);
+    hipError_t (*noise_philox)(int dtype, int K, int H, int k_offset, uint64_t seed, const DevState* st, int seed_from_state,
+                               const FilterCoefs&, void* eps, hipStream_t);
+    hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int tail_mode,
+                          const double* mean, double* log, int log_cap, int* log_count, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
 };
 
@@ -449,7 +520,8 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
 }
 
 template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArgs& a, hipStream_t s) {
-    const dim3 grid((a.K + 63) / 64), block(64);
+    static const int lanes = [] { const char* e = getenv("MPPI_LANES_PER_WAVE"); int v = e ? atoi(e) : 64; return (v >= 1 && v <= 64) ? v : 64; }();
+    const dim3 grid((a.K + lanes - 1) / lanes), block(lanes);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((rollout_kernel<float, MD>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
                            a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status);
@@ -469,14 +541,20 @@ static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H
     return hipGetLastError();
 }
 template <class MD>
-static hipError_t launch_noise_philox(int dtype, int K, int H, int k_offset, uint64_t seed, const FilterCoefs& fc, void* eps,
-                                      hipStream_t s) {
-    const dim3 grid((K + 63) / 64), block(64);
+static hipError_t launch_noise_philox(int dtype, int K, int H, int k_offset, uint64_t seed, const DevState* st,
+                                      int seed_from_state, const FilterCoefs& fc, void* eps, hipStream_t s) {
+    const dim3 grid((K * MD::NV + 255) / 256), block(256);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((noise_philox_kernel<float, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, fc, (float*)eps);
+        hipLaunchKernelGGL((noise_philox_kernel<float, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (float*)eps);
     else
-        hipLaunchKernelGGL((noise_philox_kernel<double, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, fc, (double*)eps);
+        hipLaunchKernelGGL((noise_philox_kernel<double, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (double*)eps);
+    return hipGetLastError();
+}
+template <class MD>
+static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int tail_mode,
+                                 const double* mean, double* log, int log_cap, int* log_count, hipStream_t s) {
+    hipLaunchKernelGGL((advance_kernel<MD>), dim3(1), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
     return hipGetLastError();
 }
 template <class MD>
@@ -486,7 +564,7 @@ static hipError_t launch_env_step(const double* in, int reward_type, int has_ref
 }
 template <class MD> static ModelOps make_ops() {
     return {MD::name, MD::NV, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
-            &launch_env_step<MD>};
+            &launch_advance<MD>, &launch_env_step<MD>};
 }
 static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>()};
 
@@ -521,6 +599,8 @@ struct mppi_planner {
     void* d_obs;           // T [K][H][2M+6]
     void* d_rew;           // T [K][H]
     int* d_status;
+    double* d_log;         // [LOG_CAP][3M+7] real-env log ring of mppi_advance
+    int* d_log_count;
     int explicit_act;
     FilterCoefs fc;
     hipGraphExec_t graph;
@@ -591,6 +671,9 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     HIP_OK(hipMemset(p->d_result, 0, 2 * 8));
     HIP_OK(hipMalloc(&p->d_status, 4));
     HIP_OK(hipMemset(p->d_status, 0, 4));
+    HIP_OK(hipMalloc(&p->d_log, (size_t)MPPI_LOG_CAP * (3 * p->nv + 7) * 8));
+    HIP_OK(hipMalloc(&p->d_log_count, 4));
+    HIP_OK(hipMemset(p->d_log_count, 0, 4));
     if (cfg->dump) {
         HIP_OK(hipMalloc(&p->d_obs, K * cfg->H * OD * p->esz));
         HIP_OK(hipMalloc(&p->d_rew, K * cfg->H * p->esz));
@@ -615,7 +698,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     delete p->prof_events;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
-                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status};
+                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     (void)hipStreamDestroy(p->stream);
@@ -684,12 +767,43 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) {
     return 0;
 }
 
-int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream) {
+static int generate_noise(mppi_planner* p, uint64_t seed, int seed_from_state, void* stream) {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
-    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->cfg.k_offset, seed, p->fc, p->d_eps,
-                                       pick(p, stream)));
+    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->cfg.k_offset, seed, p->d_state, seed_from_state,
+                                       p->fc, p->d_eps, pick(p, stream)));
     p->explicit_act = 0;
+    return 0;
+}
+int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream) { return generate_noise(p, seed, 0, stream); }
+int mppi_generate_noise_step(mppi_planner* p, uint64_t seed, void* stream) { return generate_noise(p, seed, 1, stream); }
+
+int mppi_advance(mppi_planner* p, void* stream) {
+    if (!p) return fail(-1, "null argument");
+    if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->cfg.default_act, p->d_mean,
+                                  p->d_log, MPPI_LOG_CAP, p->d_log_count, pick(p, stream)));
+    return 0;
+}
+
+int mppi_read_log(mppi_planner* p, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total) {
+    if (!p || !rows || !n_rows || max_rows < 0) return fail(-1, "bad argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    HIP_OK(hipDeviceSynchronize());
+    int count = 0;
+    HIP_OK(hipMemcpy(&count, p->d_log_count, 4, hipMemcpyDeviceToHost));
+    const int row = 3 * p->nv + 7;
+    int n = count < MPPI_LOG_CAP ? count : MPPI_LOG_CAP;
+    if (n > max_rows) n = max_rows;
+    // the n most recent rows, oldest first
+    for (int i = 0; i < n; i++) {
+        const int src = (count - n + i) % MPPI_LOG_CAP;
+        HIP_OK(hipMemcpy(rows + (size_t)i * row, p->d_log + (size_t)src * row, (size_t)row * 8, hipMemcpyDeviceToHost));
+    }
+    *n_rows = n;
+    if (total) *total = count;
     return 0;
 }
 

@@ -131,6 +131,24 @@ class DevicePlanner:
     def generate_noise(self, seed, stream=None):
         L.check(L.lib().mppi_generate_noise(self._h, int(seed) & (2 ** 64 - 1), stream))
 
+    def generate_noise_step(self, seed, stream=None):
+        """Philox stream keyed by seed + the planner's current timestep (read on the device)."""
+        L.check(L.lib().mppi_generate_noise_step(self._h, int(seed) & (2 ** 64 - 1), stream))
+
+    def advance(self, stream=None):
+        """Device-resident advance_time: real-env fp64 step with act_sequence[0], log, shift."""
+        L.check(L.lib().mppi_advance(self._h, stream))
+
+    def read_log(self, max_rows=4096):
+        """Most recent rows of the real-env log, oldest first: dict of arrays + total count."""
+        nv = self.nv
+        rows = np.empty((max_rows, 3 * nv + 7))
+        n, total = C.c_int32(), C.c_int32()
+        L.check(L.lib().mppi_read_log(self._h, L.ptr(rows), int(max_rows), C.byref(n), C.byref(total)))
+        r = rows[:n.value]
+        return dict(qpos=r[:, :nv], qvel=r[:, nv:2 * nv], hand=r[:, 2 * nv:2 * nv + 3], target=r[:, 2 * nv + 3:2 * nv + 6],
+                    reward=r[:, 2 * nv + 6], action=r[:, 2 * nv + 7:], total=total.value)
+
     def upload_actions(self, act):
         act = L.f64(act)
         assert act.shape == (self.K, self.H, self.nv), act.shape

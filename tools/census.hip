@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(64) c_mass(const float* in, float* out) {
 __global__ void __launch_bounds__(64) c_chol(const float* in, float* out) {
     float A[NV][NV], b[NV];
     static_for<NV>([&](auto I) { b[I] = in[(49 + I) * 64 + threadIdx.x]; static_for<I + 1>([&](auto J) { A[I][J] = in[(I * NV + J) * 64 + threadIdx.x]; }); });
-    S::chol_solve(A, b);
+    float dg[NV];
+    static_for<NV>([&](auto I) { dg[I] = in[(60 + I) * 64 + threadIdx.x]; });
+    S::chol_solve<false>(A, dg, 0.f, dg, b);
     static_for<NV>([&](auto I) { out[I * 64 + threadIdx.x] = b[I]; });
 }
 __global__ void __launch_bounds__(64) c_substep(const float* in, float* out) {

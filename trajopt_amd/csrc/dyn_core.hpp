@@ -75,6 +75,15 @@ MPPI_HD double rcp_t(double x) { return 1.0 / x; }
 MPPI_HD float abs_t(float x) { return fabsf(x); }
 MPPI_HD double abs_t(double x) { return fabs(x); }
 
+// true if the predicate holds on any active lane of the wave (host: the lane itself)
+MPPI_HD bool wave_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(x) != 0ull;
+#else
+    return x;
+#endif
+}
+
 constexpr int sym_idx(int i, int j) { return i == j ? i : i + j + 2; }   // xx yy zz xy xz yz
 
 template <class T> struct Vec3 { T v[3]; };
@@ -193,15 +202,18 @@ template <class T, class MD> struct Step {
             constexpr int i = Ic;
             Dl[i] = T(0); arl[i] = T(0); sg[i] = T(1);
             if constexpr (MD::limited[i] != 0) {
+                // at most one side can be violated; evaluated without branches
                 const T lo = q[i] - T(MD::range_lo[i]);
                 const T hi = T(MD::range_hi[i]) - q[i];
-                const bool blo = lo < T(0), bhi = hi < T(0);
-                if (blo || bhi) {
-                    const T pos = blo ? lo : hi;
-                    sg[i] = blo ? T(1) : T(-1);
-                    row_constants(pos, sg[i] * qd[i], T(MD::dof_invweight[i]), Dl[i], arl[i]);
-                    any_row = true;
-                }
+                const bool blo = lo < hi;
+                const T pos = blo ? lo : hi;
+                sg[i] = blo ? T(1) : T(-1);
+                T D, ar;
+                row_constants(pos, sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
+                const bool on = pos < T(0);
+                Dl[i] = on ? D : T(0);
+                arl[i] = on ? ar : T(0);
+                any_row |= on;
             }
         });
         T Jc[NV], Dc = T(0), arc = T(0);
@@ -238,16 +250,22 @@ template <class T, class MD> struct Step {
             bool actl[NV], actc = (Dc > T(0)) && ((act_mask >> NV) & 1u);
             static_for<NV>([&](auto Ic) { actl[Ic] = (Dl[Ic] > T(0)) && ((act_mask >> Ic) & 1u); });
             T acc[NV], resl[NV], resc = T(0);
+            const bool wave_contact = wave_any(Dc > T(0));
             for (;;) {
                 sweeps++;
-                T A[NV][NV];
+                T dg[NV];
                 static_for<NV>([&](auto Ic) {
                     constexpr int i = Ic;
-                    static_for<i + 1>([&](auto Jn) { A[i][Jn] = M[i][Jn] + (actc ? Dc * Jc[i] * Jc[Jn] : T(0)); });
-                    A[i][i] += actl[i] ? Dl[i] : T(0);
-                    acc[i] = fs[i] + (actl[i] ? sg[i] * Dl[i] * arl[i] : T(0)) + (actc ? Dc * arc * Jc[i] : T(0));
+                    dg[i] = actl[i] ? Dl[i] : T(0);
+                    acc[i] = fs[i] + sg[i] * dg[i] * arl[i];
                 });
-                chol_solve(A, acc);
+                if (wave_contact) {
+                    const T dc = actc ? Dc : T(0);
+                    static_for<NV>([&](auto Ic) { acc[Ic] += dc * arc * Jc[Ic]; });
+                    chol_solve<true>(M, dg, dc, Jc, acc);
+                } else {
+                    chol_solve<false>(M, dg, T(0), Jc, acc);
+                }
                 bool changed = false;
                 static_for<NV>([&](auto Ic) {
                     constexpr int i = Ic;
@@ -289,13 +307,13 @@ template <class T, class MD> struct Step {
         sweeps_out = sweeps;
 
         // ---- semi-implicit Euler with implicit joint damping ----------------------------------
-        T qacc[NV];
+        T qacc[NV], hb[NV];
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
-            M[i][i] += T(MD::H) * T(MD::damping[i]);
+            hb[i] = T(MD::H * MD::damping[i]);
             qacc[i] = fs[i] + fc[i];
         });
-        chol_solve(M, qacc);
+        chol_solve<false>(M, hb, T(0), hb, qacc);
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             qd[i] = qd[i] + T(MD::H) * qacc[i];
@@ -430,42 +448,44 @@ template <class T, class MD> struct Step {
         const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]), mid = T(MD::solimp[3]);
         static_assert(MD::solimp[4] == 2.0, "impedance power other than 2 is not compiled in");
         const T u = abs_t(x) * T(1.0 / MD::solimp[2]);
-        T imp = dmax;
-        if (u < T(1)) {
-            T y;
-            if (u <= mid) y = u * u * T(1.0 / MD::solimp[3]);
-            else { const T w = T(1) - u; y = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3])); }
-            imp = d0 + y * (dmax - d0);
-        }
+        const T w = T(1) - u;
+        const T ylo = u * u * T(1.0 / MD::solimp[3]);
+        const T yhi = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3]));
+        const T y = (u <= mid) ? ylo : yhi;
+        const T imp = (u < T(1)) ? d0 + y * (dmax - d0) : dmax;
         aref = -T(MD::solref_b) * vel - T(MD::solref_k) * imp * x;
         D = imp * rcp_t((T(1) - imp) * invweight);
     }
 
-    // in-place Cholesky of the lower triangle of A, then solve A x = b (b overwritten)
-    static MPPI_HD void chol_solve(T (&A)[NV][NV], T (&b)[NV]) {
-        T inv[NV];
+    // solve (M + diag(dg) + dc * Jc Jc^T) x = b by Cholesky; M (lower triangle) is read, not modified;
+    // b is overwritten with x
+    template <bool CONTACT>
+    static MPPI_HD void chol_solve(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&b)[NV]) {
+        T L[NV][NV], inv[NV];
         static_for<NV>([&](auto Jn) {
             constexpr int j = Jn;
-            T s = A[j][j];
-            static_for<j>([&](auto Kn) { s -= A[j][Kn] * A[j][Kn]; });
+            T s = M[j][j] + dg[j];
+            if constexpr (CONTACT) s += dc * Jc[j] * Jc[j];
+            static_for<j>([&](auto Kn) { s -= L[j][Kn] * L[j][Kn]; });
             inv[j] = rsqrt_t(s);
             static_for<NV - 1 - j>([&](auto In) {
                 constexpr int i = j + 1 + In;
-                T t = A[i][j];
-                static_for<j>([&](auto Kn) { t -= A[i][Kn] * A[j][Kn]; });
-                A[i][j] = t * inv[j];
+                T t = M[i][j];
+                if constexpr (CONTACT) t += dc * Jc[i] * Jc[j];
+                static_for<j>([&](auto Kn) { t -= L[i][Kn] * L[j][Kn]; });
+                L[i][j] = t * inv[j];
             });
         });
         static_for<NV>([&](auto In) {
             constexpr int i = In;
             T t = b[i];
-            static_for<i>([&](auto Kn) { t -= A[i][Kn] * b[Kn]; });
+            static_for<i>([&](auto Kn) { t -= L[i][Kn] * b[Kn]; });
             b[i] = t * inv[i];
         });
         static_for<NV>([&](auto In) {
             constexpr int i = NV - 1 - In;
             T t = b[i];
-            static_for<NV - 1 - i>([&](auto Kn) { constexpr int k = i + 1 + Kn; t -= A[k][i] * b[k]; });
+            static_for<NV - 1 - i>([&](auto Kn) { constexpr int k = i + 1 + Kn; t -= L[k][i] * b[k]; });
             b[i] = t * inv[i];
         });
     }

@@ -193,12 +193,19 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     const T gm = T(gamma);
     T ret = T(0), g = T(1);
     unsigned act_mask = ~0u;
+    // the next step's noise and base action are fetched one step ahead: they do not depend on the
+    // state, and a lone wave has nobody to hide a load's latency behind
+    T e_nx[NV];
+    double b_nx[NV];
+    static_for<NV>([&](auto Jc) { e_nx[Jc] = eps[(size_t)Jc * K + k]; b_nx[Jc] = base[Jc]; });
     for (int t = 0; t < H; t++) {
         T a[NV];
+        static_for<NV>([&](auto Jc) { a[Jc] = explicit_act ? e_nx[Jc] : T(b_nx[Jc]) + e_nx[Jc]; });
+        const int tn = (t + 1 < H) ? t + 1 : t;
         static_for<NV>([&](auto Jc) {
             constexpr int j = Jc;
-            const T e = eps[((size_t)t * NV + j) * K + k];
-            a[j] = explicit_act ? e : T(base[t * NV + j]) + e;
+            e_nx[j] = eps[((size_t)tn * NV + j) * K + k];
+            b_nx[j] = base[tn * NV + j];
         });
         T rr[3] = {T(0), T(0), T(0)};
         if (ref_len > 0) {

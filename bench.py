@@ -111,8 +111,12 @@ def main():
     from trajopt_amd.device import DeviceModel, DevicePlanner
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # MPPI_BENCH_SHARDED=1 exercises the sharded code path (partials, all-gather, merge) on one rank
+    sharded = world > 1 or os.environ.get("MPPI_BENCH_SHARDED") == "1"
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dm = DeviceModel.get("reacher_7dof")
     p = DevicePlanner(dm, K_PER_GPU, H, kappa=KAPPA, gamma=GAMMA, sigma=FILTER[0], betas=FILTER[1:],
@@ -122,14 +126,14 @@ def main():
     p.set_base_actions(np.zeros((H, M)))
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
-    if world > 1:
+    if sharded:
         part = p.partials_tensor()
         gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
 
     def planning_step():
         # everything below is enqueued on one stream; there is no host synchronisation inside a step
         p.generate_noise_step(SEED, sptr)            # Philox key = SEED + current timestep (read on the device)
-        if world == 1:
+        if not sharded:
             p.iterate(1, sptr)                       # rollouts + weights + weighted sum + merge
         else:
             p.local_partials(sptr)
@@ -138,7 +142,7 @@ def main():
         p.advance(sptr)                              # real env fp64 step with act_sequence[0], log, horizon shift
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +158,7 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms, launches = p.profile_read()
     p.profile(False)
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -190,7 +194,7 @@ def main():
         out["config"]["real_env_steps_logged"] = int(log["total"])
         out["config"]["final_hand_target_distance"] = float(np.linalg.norm(log["hand"][-1] - log["target"][-1]))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

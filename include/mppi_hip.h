@@ -29,6 +29,7 @@ enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_REWARD_DENSE = 0, MPPI_REWARD_SPARSE = 1, MPPI_REWARD_TRACKING = 2, MPPI_REWARD_COOLING = 3 };
 enum { MPPI_TAIL_REPEAT = 0, MPPI_TAIL_MEAN = 1 };
 enum {
+    /* sizes are per planner; a handle with P batched planners returns P of each, back to back */
     MPPI_READ_RETURNS = 0,      /* double[K]            discounted return of every local sample        */
     MPPI_READ_ACT_SEQ = 1,      /* double[H*M]          current act_sequence                            */
     MPPI_READ_ARGMAX = 2,       /* int64[1]             global index of the best sample (first on ties) */
@@ -86,6 +87,9 @@ typedef struct mppi_planner_cfg {
     int32_t default_act;   /* MPPI_TAIL_*                                                  */
     int32_t k_offset;      /* global index of local sample 0 (sharded planners)            */
     int32_t dump;          /* keep next_observations / rewards of every rollout            */
+    int32_t P;             /* independent planners batched in this handle (0 or 1: one).   */
+    int32_t reserved;      /*   Every per-planner array argument / result then holds the P */
+                           /*   planners back to back; noise streams differ per planner.   */
     double kappa;
     double gamma;
     double sigma[MPPI_MAXV];   /* filter_coefs[0]                                          */
@@ -112,7 +116,7 @@ void mppi_planner_destroy(mppi_planner* p);
 /* `start_state` of `gather_paths_parallel` / `set_env_state` at the top of every rollout
  * (trajopt/utils.py:76, trajopt/envs/reacher_env.py:151-160). */
 int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel, const double* target3,
-                         int32_t timestep);
+                         const int32_t* timestep);
 /* `base_act` of `gather_paths_parallel` = `MPPI.act_sequence` (trajopt/algos/mppi.py:47,113). */
 int mppi_set_base_actions(mppi_planner* p, const double* act_HxM);
 /* `reference` / `alpha` of the tracking and cooling rewards (trajopt/envs/reacher_env.py:60-79);
@@ -157,7 +161,7 @@ int mppi_shift(mppi_planner* p, const double* override_seq_HxM, void* stream);
  * (3M+7 doubles) to a ring of MPPI_LOG_CAP rows, and shifts the horizon.  No host round trip.
  * mppi_read_log copies the most recent rows (oldest first); total = rows ever written. */
 int mppi_advance(mppi_planner* p, void* stream);
-int mppi_read_log(mppi_planner* p, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
+int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
 
 int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);
 

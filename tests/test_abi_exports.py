@@ -31,7 +31,7 @@ def test_struct_layouts_match_the_header():
     nd = 32
     model = 64 + 4 * 2 + 4 * nd * 2 + 4 * 2 + 8 + 8 * (3 * nd * 3 + 6 * nd + 9 * nd) + 8 * (3 + 4 + 3 + 2 + 5)
     assert ctypes.sizeof(_lib.ModelDescC) == model
-    assert ctypes.sizeof(_lib.PlannerCfgC) == 4 * 8 + 8 * 2 + 8 * (nd + 3 + nd)
+    assert ctypes.sizeof(_lib.PlannerCfgC) == 4 * 10 + 8 * 2 + 8 * (nd + 3 + nd)
 
 
 def test_philox_known_answers():

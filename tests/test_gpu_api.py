@@ -181,3 +181,42 @@ def test_dense_planning_reaches_the_target():
     final = float(ag.sol_obs[-1][-1])
     assert total > -350.0, total
     assert final < 0.06, final
+
+
+def test_continual_env_resets_target_every_50_real_steps():
+    from trajopt.envs.utils import get_environment
+    e = get_environment('continual_reacher_7dof')
+    assert e.env_name == 'continual_reacher_7dof'
+    e.reset_model(seed=5)
+    first = e.get_env_state()['target_pos'].copy()
+    for _ in range(49):
+        e.step(np.zeros(7))
+    assert np.array_equal(e.get_env_state()['target_pos'], first)
+    e.step(np.zeros(7))                                   # 50th real step draws a new target
+    assert not np.array_equal(e.get_env_state()['target_pos'], first)
+    e.real_step = False                                    # rollout envs never move the target
+    t = e.get_env_state()['target_pos'].copy()
+    for _ in range(50):
+        e.step(np.zeros(7))
+    assert np.array_equal(e.get_env_state()['target_pos'], t)
+
+
+def test_pickled_agent_resolves_through_the_trajopt_names(tmp_path):
+    """An agent pickled under the reference's module names loads back onto this implementation."""
+    import pickletools
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    e = get_environment('reacher_7dof')
+    e.reset_model(goal=(0, 0, 0))
+    ag = MPPI(e, H=8, paths_per_cpu=16, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=2)
+    ag.train_step(niter=1)
+    blob = pickle.dumps(ag, protocol=3)
+    blob = blob.replace(b"trajopt_amd.algos.mppi", b"trajopt.algos.mppi").replace(b"trajopt_amd.envs.reacher_env", b"trajopt.envs.reacher_env")
+    names = {arg for op, arg, _ in pickletools.genops(blob) if op.name == "GLOBAL"}
+    assert "trajopt.algos.mppi MPPI" in names and "trajopt.envs.reacher_env Reacher7DOFEnv" in names
+    ag2 = pickle.loads(blob)
+    assert type(ag2).__name__ == "MPPI" and len(ag2.sol_state) == 2
+    ag2.env.set_env_state(ag2.sol_state[1])
+    assert np.allclose(ag2.env.data.site_xpos[ag2.env.hand_sid], ag2.env._dev.forward_hand(ag2.sol_state[1]['qp']))
+    ag2.train_step(niter=1)
+    assert len(ag2.sol_state) == 3

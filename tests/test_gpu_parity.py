@@ -224,3 +224,80 @@ def test_device_resident_advance_matches_host_driven_loop(dev_model, oracle_sim)
     # and the logged transitions are the oracle's
     q2, v2, _, r2, _ = oracle_sim.env_step(host[-2][0], host[-2][1], tgt, host[-1][4], 3 + steps - 1)
     assert np.abs(q2 - log["qpos"][-1]).max() < 1e-10 and abs(r2 - log["reward"][-1]) < 1e-10
+
+
+def test_batched_planners_equal_independent_planners(dev_model, oracle_sim):
+    """One handle with P planners (own start state, base actions, noise) gives, planner by planner,
+    what P separate handles give; and its rollouts are the oracle's."""
+    P, K, H = 5, 96, 10
+    rs = np.random.RandomState(8)
+    q0, v0 = rs.uniform(-0.5, 0.5, (P, 7)), rs.randn(P, 7) * 0.5
+    tgt = rs.uniform(-0.1, 0.1, (P, 3))
+    ts = np.arange(P) * 3
+    base = rs.randn(P, H, 7) * 0.2
+    raw = np.stack([ref_mppi.raw_normals(100 + b, K, H, 7) for b in range(P)])
+    batch = _planner(dev_model, K, H, "f32", planners=P, gamma=0.95)
+    batch.set_start_state(q0, v0, tgt, ts)
+    batch.set_base_actions(base)
+    batch.upload_noise(raw)
+    batch.iterate(2)
+    R, seq, am = batch.returns(), batch.act_sequence(), batch.argmax()
+    assert R.shape == (P, K) and seq.shape == (P, H, 7)
+    for b in range(P):
+        one = _planner(dev_model, K, H, "f32", gamma=0.95)
+        one.set_start_state(q0[b], v0[b], tgt[b], int(ts[b]))
+        one.set_base_actions(base[b])
+        one.upload_noise(raw[b])
+        one.iterate(2)
+        assert np.array_equal(one.returns(), R[b]) and np.array_equal(one.act_sequence(), seq[b])
+        assert one.argmax() == am[b]
+        one.close()
+    # first-iteration returns against the oracle for one of the planners
+    chk = _planner(dev_model, K, H, "f32", planners=P, gamma=0.95)
+    chk.set_start_state(q0, v0, tgt, ts)
+    chk.set_base_actions(base)
+    chk.upload_noise(raw)
+    chk.rollout()
+    eps = ref_mppi.filter_noise(raw[3].copy(), FILTER)
+    R_o = oracle_sim.rollout(q0[3], v0[3], tgt[3], int(ts[3]), base[3] + eps, gamma=0.95)
+    assert (np.abs(chk.returns()[3] - R_o) / np.abs(R_o)).max() < 1e-4
+    # device-resident advance runs every planner's real env and log
+    batch.advance()
+    for b in (0, P - 1):
+        log = batch.read_log(planner=b)
+        q2, v2, _, r2, _ = oracle_sim.env_step(q0[b], v0[b], tgt[b], seq[b][0], int(ts[b]))
+        assert log["total"] == 1 and np.abs(log["qpos"][0] - q2).max() < 1e-10 and abs(log["reward"][0] - r2) < 1e-10
+    assert np.array_equal(batch.act_sequence()[1], ref_mppi.shift(seq[1], "mean", np.zeros(7)))
+    # Philox streams differ between planners of one handle
+    batch.set_base_actions(np.zeros((P, H, 7)))
+    batch.generate_noise(5)
+    z = batch.actions()
+    assert not np.array_equal(z[0], z[1])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_constraint_free_arm(dtype):
+    """The same arm with joint limits and the table contact stripped (the 'no contacts' serial arm).
+    Not pinned by any reference data: the checker is this repository's own fp64 oracle."""
+    from oracle.sim import OracleSim
+    from trajopt_amd.device import DeviceModel
+    from trajopt_amd.model import get_model
+    sim = OracleSim(get_model("reacher_7dof_free"))
+    dm = DeviceModel.get("reacher_7dof_free")
+    K, H = 128, 32
+    raw = ref_mppi.all_raw_normals(21, K, 1, H, 7)
+    act = ref_mppi.filter_noise(raw.copy(), FILTER) * 2.0
+    R_o, nobs_o, _ = sim.rollout(np.zeros(7), np.zeros(7), np.zeros(3), 0, act, dump=True, nthreads=4)
+    assert np.abs(nobs_o[:, :, :7]).max() > 2.5            # nothing holds the joints inside their former ranges
+    p = _planner(dm, K, H, dtype, dump=True, sigma=2.0 * np.ones(7))
+    p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.upload_noise(raw)
+    p.rollout()
+    nobs, R = p.next_observations(), p.returns()
+    if dtype == "f64":
+        assert np.abs(nobs - nobs_o).max() < 1e-9 and np.abs(R - R_o).max() < 1e-9
+    else:
+        assert (np.abs(nobs - nobs_o) / (1 + np.abs(nobs_o))).max() < 1e-4
+        assert (np.abs(R - R_o) / np.abs(R_o)).max() < 1e-4
+    assert int(np.argmax(R)) == int(np.argmax(R_o))

@@ -36,7 +36,8 @@ class ModelDescC(C.Structure):
 class PlannerCfgC(C.Structure):
     _fields_ = [
         ("K", _i32), ("H", _i32), ("dtype", _i32), ("device", _i32), ("reward_type", _i32),
-        ("default_act", _i32), ("k_offset", _i32), ("dump", _i32), ("kappa", _d), ("gamma", _d),
+        ("default_act", _i32), ("k_offset", _i32), ("dump", _i32), ("P", _i32), ("reserved", _i32),
+        ("kappa", _d), ("gamma", _d),
         ("sigma", _d * MAXV), ("beta", _d * 3), ("mean", _d * MAXV),
     ]
 
@@ -54,7 +55,7 @@ _PROTOS = {
     "mppi_model_destroy": (None, [_vp]),
     "mppi_planner_create": (C.c_int, [_vp, C.POINTER(PlannerCfgC), C.POINTER(_vp)]),
     "mppi_planner_destroy": (None, [_vp]),
-    "mppi_set_start_state": (C.c_int, [_vp, _vp, _vp, _vp, _i32]),
+    "mppi_set_start_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "mppi_set_base_actions": (C.c_int, [_vp, _vp]),
     "mppi_set_reference": (C.c_int, [_vp, _vp, _i32, _d]),
     "mppi_set_params": (C.c_int, [_vp, _d, _d, _i32]),
@@ -62,7 +63,7 @@ _PROTOS = {
     "mppi_generate_noise": (C.c_int, [_vp, _u64, _vp]),
     "mppi_generate_noise_step": (C.c_int, [_vp, _u64, _vp]),
     "mppi_advance": (C.c_int, [_vp, _vp]),
-    "mppi_read_log": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "mppi_read_log": (C.c_int, [_vp, _i32, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "mppi_upload_actions": (C.c_int, [_vp, _vp, _vp]),
     "mppi_rollout": (C.c_int, [_vp, _vp]),
     "mppi_iterate": (C.c_int, [_vp, _i32, _vp]),

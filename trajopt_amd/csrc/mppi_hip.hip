@@ -105,6 +105,8 @@ __global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restri
                                                           int filter, T* __restrict__ eps) {
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= K) return;
+    raw += (size_t)blockIdx.y * K * H * NV;           // planner blockIdx.y of a batched handle
+    eps += (size_t)blockIdx.y * H * NV * K;
     double e1[NV], e2[NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) e1[j] = e2[j] = 0.0;
@@ -133,6 +135,9 @@ __global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_o
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= K * NV) return;
     const int j = idx / K, k = idx - j * K;
+    const int pl = blockIdx.y;                        // planner of a batched handle: its own counter plane
+    eps += (size_t)pl * H * NV * K;
+    st += pl;
     if (seed_from_state) {
         const uint64_t s = (((uint64_t)seed_hi << 32) | seed_lo) + (uint64_t)(int64_t)st->timestep;
         seed_lo = (uint32_t)s;
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_o
     const double sigma = fc.sigma[j];
     double e1 = 0.0, e2 = 0.0;
     for (int c = 0; 4 * c < H; c++) {
-        uint32_t ctr[4] = {(uint32_t)(k_offset + k), (uint32_t)j, (uint32_t)c, 0u};
+        uint32_t ctr[4] = {(uint32_t)(k_offset + k), (uint32_t)j, (uint32_t)c, (uint32_t)pl};
         philox4x32_10(ctr, seed_lo, seed_hi);
         float z[4];
         box_muller(ctr[0], ctr[1], z[0], z[1]);
@@ -183,6 +188,12 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     constexpr int OD = 2 * NV + 6;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
+    {   // planner blockIdx.y of a batched handle
+        const size_t pl = blockIdx.y;
+        st += pl; base += pl * H * NV; eps += pl * H * NV * K; R += pl * K;
+        if (obs) obs += pl * K * H * OD;
+        if (rew) rew += pl * K * H;
+    }
     T q[NV], v[NV];
     static_for<NV>([&](auto Ic) { q[Ic] = T(st->q[Ic]); v[Ic] = T(st->v[Ic]); });
     RewardParams<T> rp;
@@ -279,6 +290,8 @@ __global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st,
     const int tid = threadIdx.x;
     double keep[PER];
     const int HM = H * NV;
+    st += blockIdx.x; base += (size_t)blockIdx.x * HM;           // one block per planner
+    log += (size_t)blockIdx.x * log_cap * ROW; log_count += blockIdx.x;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int i = tid + 256 * u;
@@ -335,8 +348,9 @@ __device__ __forceinline__ double shfl_xor_d(double x, int m) { return __shfl_xo
 
 // single block: Rmax / first arg-max over K, S[k], sum S  -> part[0..2]
 template <class T>
-__global__ void __launch_bounds__(1024) weights_kernel(const T* __restrict__ R, int K, double kappa, int k_offset,
+__global__ void __launch_bounds__(1024) weights_kernel(const T* __restrict__ R, int K, int HM, double kappa, int k_offset,
                                                        double* __restrict__ S, double* __restrict__ part) {
+    R += (size_t)blockIdx.x * K; S += (size_t)blockIdx.x * K; part += (size_t)blockIdx.x * (3 + HM);   // one block per planner
     __shared__ double s_v[16];
     __shared__ int s_i[16];
     __shared__ double s_bcast;
@@ -380,6 +394,8 @@ __global__ void __launch_bounds__(256) wsum_kernel(const double* __restrict__ S,
                                                    double* __restrict__ part) {
     __shared__ double s_v[4];
     const int hm = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HM = gridDim.x;
+    S += (size_t)blockIdx.y * K; eps += (size_t)blockIdx.y * HM * K; part += (size_t)blockIdx.y * (3 + HM);
     const T* e = eps + (size_t)hm * K;
     double num = 0.0;
     for (int k = tid; k < K; k += 256) num += S[k] * (double)e[k];
@@ -393,7 +409,10 @@ __global__ void __launch_bounds__(256) wsum_kernel(const double* __restrict__ S,
 // act_sequence = sum_k S_k (base + eps_k) / (sum S + 1e-6) from nranks shard statistics, rank order
 __global__ void merge_kernel(const double* __restrict__ gathered, int nranks, int HM, double kappa,
                              double* __restrict__ base, double* __restrict__ result) {
-    const int stride = 3 + HM;
+    const int stride = (3 + HM) * gridDim.y;        // a rank's row holds its gridDim.y planners back to back
+    gathered += (size_t)blockIdx.y * (3 + HM);
+    base += (size_t)blockIdx.y * HM;
+    result += 2 * blockIdx.y;
     double gmax = -DBL_MAX, gidx = 0.0;
     for (int r = 0; r < nranks; r++) {
         const double m = gathered[(size_t)r * stride];
@@ -413,6 +432,8 @@ __global__ void merge_kernel(const double* __restrict__ gathered, int nranks, in
 // tmp[t] = src[t+1], tail = previous last row (repeat) or mean
 __global__ void shift_kernel(const double* __restrict__ src, int H, int M, int tail_mode, const double* __restrict__ mean,
                              double* __restrict__ dst) {
+    src += (size_t)blockIdx.y * H * M;
+    dst += (size_t)blockIdx.y * H * M;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * M; i += gridDim.x * blockDim.x) {
         const int t = i / M, j = i - t * M;
         double v;
@@ -458,7 +479,7 @@ __global__ void __launch_bounds__(256) update_direct_kernel(const double* __rest
 // ------------------------------------------------------------------------------------------
 struct RolloutArgs {
     const DevState* st; const double* base; const void* eps; const double* ref;
-    int K, H, reward_type; double gamma; int explicit_act;
+    int K, H, P, reward_type; double gamma; int explicit_act;
     void* R; void* obs; void* rew; int* status;
 };
 
@@ -467,10 +488,10 @@ struct ModelOps {
     int nv;
     bool (*matches)(const mppi_model_desc*, std::string&);
     hipError_t (*rollout)(int dtype, const RolloutArgs&, hipStream_t);
-    hipError_t (*noise_upload)(int dtype, const double* raw, int K, int H, const FilterCoefs&, int filter, void* eps, hipStream_t);
-    hipError_t (*noise_philox)(int dtype, int K, int H, int k_offset, uint64_t seed, const DevState* st, int seed_from_state,
+    hipError_t (*noise_upload)(int dtype, const double* raw, int K, int H, int P, const FilterCoefs&, int filter, void* eps, hipStream_t);
+    hipError_t (*noise_philox)(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st, int seed_from_state,
                                const FilterCoefs&, void* eps, hipStream_t);
-    hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int tail_mode,
+    hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                           const double* mean, double* log, int log_cap, int* log_count, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
 };
@@ -528,7 +549,7 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
 
 template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArgs& a, hipStream_t s) {
     static const int lanes = [] { const char* e = getenv("MPPI_LANES_PER_WAVE"); int v = e ? atoi(e) : 64; return (v >= 1 && v <= 64) ? v : 64; }();
-    const dim3 grid((a.K + lanes - 1) / lanes), block(lanes);
+    const dim3 grid((a.K + lanes - 1) / lanes, a.P), block(lanes);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((rollout_kernel<float, MD>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
                            a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status);
@@ -538,9 +559,9 @@ template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArg
     return hipGetLastError();
 }
 template <class MD>
-static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H, const FilterCoefs& fc, int filter, void* eps,
+static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H, int P, const FilterCoefs& fc, int filter, void* eps,
                                       hipStream_t s) {
-    const dim3 grid((K + 63) / 64), block(64);
+    const dim3 grid((K + 63) / 64, P), block(64);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((noise_upload_kernel<float, MD::NV>), grid, block, 0, s, raw, K, H, fc, filter, (float*)eps);
     else
@@ -548,9 +569,9 @@ static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H
     return hipGetLastError();
 }
 template <class MD>
-static hipError_t launch_noise_philox(int dtype, int K, int H, int k_offset, uint64_t seed, const DevState* st,
+static hipError_t launch_noise_philox(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st,
                                       int seed_from_state, const FilterCoefs& fc, void* eps, hipStream_t s) {
-    const dim3 grid((K * MD::NV + 255) / 256), block(256);
+    const dim3 grid((K * MD::NV + 255) / 256, P), block(256);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((noise_philox_kernel<float, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (float*)eps);
@@ -559,9 +580,9 @@ static hipError_t launch_noise_philox(int dtype, int K, int H, int k_offset, uin
     return hipGetLastError();
 }
 template <class MD>
-static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int tail_mode,
+static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                  const double* mean, double* log, int log_cap, int* log_count, hipStream_t s) {
-    hipLaunchKernelGGL((advance_kernel<MD>), dim3(1), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
+    hipLaunchKernelGGL((advance_kernel<MD>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
     return hipGetLastError();
 }
 template <class MD>
@@ -588,7 +609,7 @@ struct mppi_model {
 struct mppi_planner {
     const mppi_model* model;
     mppi_planner_cfg cfg;
-    int nv, HM;
+    int nv, HM, P;         // P = planners batched in this handle (arrays below carry a leading [P])
     size_t esz;            // sizeof(T)
     hipStream_t stream;
     DevState* d_state;
@@ -657,37 +678,39 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     p->cfg = *cfg;
     p->nv = m->ops->nv;
     p->HM = cfg->H * p->nv;
+    p->P = cfg->P > 1 ? cfg->P : 1;
+    p->cfg.P = p->P;
     p->esz = cfg->dtype == MPPI_F32 ? 4 : 8;
-    const size_t K = cfg->K, HM = p->HM, OD = 2 * p->nv + 6;
+    const size_t P = p->P;
+    const size_t K = cfg->K * P, HM = p->HM * P, OD = 2 * p->nv + 6;   // sizes over all planners
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIP_OK(hipMalloc(&p->d_state, sizeof(DevState)));
-    HIP_OK(hipMemset(p->d_state, 0, sizeof(DevState)));
+    HIP_OK(hipMalloc(&p->d_state, sizeof(DevState) * P));
+    HIP_OK(hipMemset(p->d_state, 0, sizeof(DevState) * P));
     HIP_OK(hipMalloc(&p->d_base, HM * 8));
     HIP_OK(hipMalloc(&p->d_base_tmp, HM * 8));
     HIP_OK(hipMalloc(&p->d_mean, MPPI_MAXV * 8));
     HIP_OK(hipMemcpy(p->d_mean, cfg->mean, MPPI_MAXV * 8, hipMemcpyHostToDevice));
-    HIP_OK(hipMalloc(&p->d_eps, HM * K * p->esz));
-    HIP_OK(hipMemset(p->d_eps, 0, HM * K * p->esz));
-    HIP_OK(hipMalloc(&p->d_raw, HM * K * 8));
+    HIP_OK(hipMalloc(&p->d_eps, (size_t)p->HM * K * p->esz));
+    HIP_OK(hipMemset(p->d_eps, 0, (size_t)p->HM * K * p->esz));
     HIP_OK(hipMalloc(&p->d_R, K * p->esz));
     HIP_OK(hipMemset(p->d_R, 0, K * p->esz));
     HIP_OK(hipMalloc(&p->d_S, K * 8));
-    HIP_OK(hipMalloc(&p->d_part, (3 + HM) * 8));
-    HIP_OK(hipMemset(p->d_part, 0, (3 + HM) * 8));
-    HIP_OK(hipMalloc(&p->d_result, 2 * 8));
-    HIP_OK(hipMemset(p->d_result, 0, 2 * 8));
+    HIP_OK(hipMalloc(&p->d_part, (3 * P + HM) * 8));
+    HIP_OK(hipMemset(p->d_part, 0, (3 * P + HM) * 8));
+    HIP_OK(hipMalloc(&p->d_result, 2 * 8 * P));
+    HIP_OK(hipMemset(p->d_result, 0, 2 * 8 * P));
     HIP_OK(hipMalloc(&p->d_status, 4));
     HIP_OK(hipMemset(p->d_status, 0, 4));
-    HIP_OK(hipMalloc(&p->d_log, (size_t)MPPI_LOG_CAP * (3 * p->nv + 7) * 8));
-    HIP_OK(hipMalloc(&p->d_log_count, 4));
-    HIP_OK(hipMemset(p->d_log_count, 0, 4));
+    HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (3 * p->nv + 7) * 8));
+    HIP_OK(hipMalloc(&p->d_log_count, 4 * P));
+    HIP_OK(hipMemset(p->d_log_count, 0, 4 * P));
     if (cfg->dump) {
         HIP_OK(hipMalloc(&p->d_obs, K * cfg->H * OD * p->esz));
         HIP_OK(hipMalloc(&p->d_rew, K * cfg->H * p->esz));
     }
     // act_sequence = ones((H, m)) * mean
     std::vector<double> base(HM);
-    for (int t = 0; t < cfg->H; t++)
+    for (size_t t = 0; t < (size_t)cfg->H * P; t++)
         for (int j = 0; j < p->nv; j++) base[t * p->nv + j] = cfg->mean[j];
     HIP_OK(hipMemcpy(p->d_base, base.data(), HM * 8, hipMemcpyHostToDevice));
     for (int j = 0; j < MPPI_MAXV; j++) p->fc.sigma[j] = cfg->sigma[j];
@@ -712,17 +735,20 @@ void mppi_planner_destroy(mppi_planner* p) {
     delete p;
 }
 
-int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel, const double* target3, int32_t timestep) {
-    if (!p || !qpos || !qvel || !target3) return fail(-1, "null argument");
+int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel, const double* target3,
+                         const int32_t* timestep) {
+    if (!p || !qpos || !qvel || !target3 || !timestep) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
-    // keep alpha / ref_len: fetch-modify-store through a host copy of the small struct
-    DevState s;
-    HIP_OK(hipMemcpyAsync(&s, p->d_state, sizeof(s), hipMemcpyDeviceToHost, p->stream));
+    // keep alpha / ref_len: fetch-modify-store through a host copy of the small structs
+    std::vector<DevState> s(p->P);
+    HIP_OK(hipMemcpyAsync(s.data(), p->d_state, sizeof(DevState) * p->P, hipMemcpyDeviceToHost, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
-    for (int i = 0; i < p->nv; i++) { s.q[i] = qpos[i]; s.v[i] = qvel[i]; }
-    for (int c = 0; c < 3; c++) s.target[c] = target3[c];
-    s.timestep = timestep;
-    HIP_OK(hipMemcpyAsync(p->d_state, &s, sizeof(s), hipMemcpyHostToDevice, p->stream));
+    for (int b = 0; b < p->P; b++) {
+        for (int i = 0; i < p->nv; i++) { s[b].q[i] = qpos[b * p->nv + i]; s[b].v[i] = qvel[b * p->nv + i]; }
+        for (int c = 0; c < 3; c++) s[b].target[c] = target3[3 * b + c];
+        s[b].timestep = timestep[b];
+    }
+    HIP_OK(hipMemcpyAsync(p->d_state, s.data(), sizeof(DevState) * p->P, hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
     return 0;
 }
@@ -730,7 +756,7 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
 int mppi_set_base_actions(mppi_planner* p, const double* act) {
     if (!p || !act) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
-    HIP_OK(hipMemcpyAsync(p->d_base, act, (size_t)p->HM * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipMemcpyAsync(p->d_base, act, (size_t)p->HM * p->P * 8, hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
     return 0;
 }
@@ -747,11 +773,10 @@ int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alp
         p->graph_valid = false;
     }
     if (T > 0) HIP_OK(hipMemcpy(p->d_ref, ref, (size_t)T * 3 * 8, hipMemcpyHostToDevice));
-    DevState s;
-    HIP_OK(hipMemcpy(&s, p->d_state, sizeof(s), hipMemcpyDeviceToHost));
-    s.alpha = alpha;
-    s.ref_len = T;
-    HIP_OK(hipMemcpy(p->d_state, &s, sizeof(s), hipMemcpyHostToDevice));
+    std::vector<DevState> s(p->P);
+    HIP_OK(hipMemcpy(s.data(), p->d_state, sizeof(DevState) * p->P, hipMemcpyDeviceToHost));
+    for (auto& x : s) { x.alpha = alpha; x.ref_len = T; }
+    HIP_OK(hipMemcpy(p->d_state, s.data(), sizeof(DevState) * p->P, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -767,8 +792,9 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) {
     if (!p || !raw) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
-    HIP_OK(hipMemcpyAsync(p->d_raw, raw, (size_t)p->HM * p->cfg.K * 8, hipMemcpyHostToDevice, s));
-    HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->fc, 1, p->d_eps, s));
+    if (!p->d_raw) HIP_OK(hipMalloc(&p->d_raw, (size_t)p->HM * p->cfg.K * p->P * 8));      // host-upload staging, on first use
+    HIP_OK(hipMemcpyAsync(p->d_raw, raw, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 1, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));     // the host buffer may be reused by the caller
     p->explicit_act = 0;
     return 0;
@@ -777,7 +803,7 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) {
 static int generate_noise(mppi_planner* p, uint64_t seed, int seed_from_state, void* stream) {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
-    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->cfg.k_offset, seed, p->d_state, seed_from_state,
+    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->P, p->cfg.k_offset, seed, p->d_state, seed_from_state,
                                        p->fc, p->d_eps, pick(p, stream)));
     p->explicit_act = 0;
     return 0;
@@ -789,25 +815,26 @@ int mppi_advance(mppi_planner* p, void* stream) {
     if (!p) return fail(-1, "null argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance");
     HIP_OK(hipSetDevice(p->cfg.device));
-    HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->cfg.default_act, p->d_mean,
+    HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
                                   p->d_log, MPPI_LOG_CAP, p->d_log_count, pick(p, stream)));
     return 0;
 }
 
-int mppi_read_log(mppi_planner* p, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total) {
-    if (!p || !rows || !n_rows || max_rows < 0) return fail(-1, "bad argument");
+int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total) {
+    if (!p || !rows || !n_rows || max_rows < 0 || planner < 0 || planner >= p->P) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
     HIP_OK(hipDeviceSynchronize());
     int count = 0;
-    HIP_OK(hipMemcpy(&count, p->d_log_count, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&count, p->d_log_count + planner, 4, hipMemcpyDeviceToHost));
     const int row = 3 * p->nv + 7;
+    const double* ring = p->d_log + (size_t)planner * MPPI_LOG_CAP * row;
     int n = count < MPPI_LOG_CAP ? count : MPPI_LOG_CAP;
     if (n > max_rows) n = max_rows;
     // the n most recent rows, oldest first
     for (int i = 0; i < n; i++) {
         const int src = (count - n + i) % MPPI_LOG_CAP;
-        HIP_OK(hipMemcpy(rows + (size_t)i * row, p->d_log + (size_t)src * row, (size_t)row * 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(rows + (size_t)i * row, ring + (size_t)src * row, (size_t)row * 8, hipMemcpyDeviceToHost));
     }
     *n_rows = n;
     if (total) *total = count;
@@ -818,8 +845,9 @@ int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) {
     if (!p || !act) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
-    HIP_OK(hipMemcpyAsync(p->d_raw, act, (size_t)p->HM * p->cfg.K * 8, hipMemcpyHostToDevice, s));
-    HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->fc, 0, p->d_eps, s));
+    if (!p->d_raw) HIP_OK(hipMalloc(&p->d_raw, (size_t)p->HM * p->cfg.K * p->P * 8));
+    HIP_OK(hipMemcpyAsync(p->d_raw, act, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 0, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));
     p->explicit_act = 1;
     return 0;
@@ -834,7 +862,7 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
     }
     RolloutArgs a;
     a.st = p->d_state; a.base = p->d_base; a.eps = p->d_eps; a.ref = p->d_ref;
-    a.K = p->cfg.K; a.H = p->cfg.H; a.reward_type = p->cfg.reward_type; a.gamma = p->cfg.gamma;
+    a.K = p->cfg.K; a.H = p->cfg.H; a.P = p->P; a.reward_type = p->cfg.reward_type; a.gamma = p->cfg.gamma;
     a.explicit_act = p->explicit_act;
     a.R = p->d_R; a.obs = p->d_obs; a.rew = p->d_rew; a.status = p->d_status;
     HIP_OK(p->model->ops->rollout(p->cfg.dtype, a, s));
@@ -848,20 +876,20 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
 
 static int launch_partials(mppi_planner* p, hipStream_t s) {
     if (p->cfg.dtype == MPPI_F32) {
-        hipLaunchKernelGGL((weights_kernel<float>), dim3(1), dim3(1024), 0, s, (const float*)p->d_R, p->cfg.K, p->cfg.kappa,
+        hipLaunchKernelGGL((weights_kernel<float>), dim3(p->P), dim3(1024), 0, s, (const float*)p->d_R, p->cfg.K, p->HM, p->cfg.kappa,
                            p->cfg.k_offset, p->d_S, p->d_part);
-        hipLaunchKernelGGL((wsum_kernel<float>), dim3(p->HM), dim3(256), 0, s, p->d_S, (const float*)p->d_eps, p->cfg.K, p->d_part);
+        hipLaunchKernelGGL((wsum_kernel<float>), dim3(p->HM, p->P), dim3(256), 0, s, p->d_S, (const float*)p->d_eps, p->cfg.K, p->d_part);
     } else {
-        hipLaunchKernelGGL((weights_kernel<double>), dim3(1), dim3(1024), 0, s, (const double*)p->d_R, p->cfg.K, p->cfg.kappa,
+        hipLaunchKernelGGL((weights_kernel<double>), dim3(p->P), dim3(1024), 0, s, (const double*)p->d_R, p->cfg.K, p->HM, p->cfg.kappa,
                            p->cfg.k_offset, p->d_S, p->d_part);
-        hipLaunchKernelGGL((wsum_kernel<double>), dim3(p->HM), dim3(256), 0, s, p->d_S, (const double*)p->d_eps, p->cfg.K, p->d_part);
+        hipLaunchKernelGGL((wsum_kernel<double>), dim3(p->HM, p->P), dim3(256), 0, s, p->d_S, (const double*)p->d_eps, p->cfg.K, p->d_part);
     }
     HIP_OK(hipGetLastError());
     return 0;
 }
 
 static int launch_merge(mppi_planner* p, const double* gathered, int nranks, hipStream_t s) {
-    hipLaunchKernelGGL(merge_kernel, dim3((p->HM + 255) / 256), dim3(256), 0, s, gathered, nranks, p->HM, p->cfg.kappa,
+    hipLaunchKernelGGL(merge_kernel, dim3((p->HM + 255) / 256, p->P), dim3(256), 0, s, gathered, nranks, p->HM, p->cfg.kappa,
                        p->d_base, p->d_result);
     HIP_OK(hipGetLastError());
     return 0;
@@ -886,7 +914,7 @@ int mppi_local_partials(mppi_planner* p, void* stream) {
 int mppi_partials_ptr(mppi_planner* p, void** ptr, size_t* bytes) {
     if (!p || !ptr || !bytes) return fail(-1, "null argument");
     *ptr = p->d_part;
-    *bytes = (size_t)(3 + p->HM) * 8;
+    *bytes = (size_t)(3 + p->HM) * p->P * 8;
     return 0;
 }
 
@@ -937,13 +965,13 @@ int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) {
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     if (override_seq) {
-        HIP_OK(hipMemcpyAsync(p->d_base, override_seq, (size_t)p->HM * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(p->d_base, override_seq, (size_t)p->HM * p->P * 8, hipMemcpyHostToDevice, s));
         HIP_OK(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(shift_kernel, dim3((p->HM + 255) / 256), dim3(256), 0, s, p->d_base, p->cfg.H, p->nv, p->cfg.default_act,
+    hipLaunchKernelGGL(shift_kernel, dim3((p->HM + 255) / 256, p->P), dim3(256), 0, s, p->d_base, p->cfg.H, p->nv, p->cfg.default_act,
                        p->d_mean, p->d_base_tmp);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(p->d_base, p->d_base_tmp, (size_t)p->HM * 8, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(p->d_base, p->d_base_tmp, (size_t)p->HM * p->P * 8, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -995,64 +1023,63 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) {
     if (!p || !dst) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
-    const size_t K = p->cfg.K, H = p->cfg.H, HM = p->HM, OD = 2 * p->nv + 6;
+    // every selector returns the P planners of the handle back to back
+    const size_t P = p->P, K = p->cfg.K, H = p->cfg.H, HM = p->HM, OD = 2 * p->nv + 6;
     auto need = [&](size_t n) { return bytes == n; };
     switch (what) {
     case MPPI_READ_RETURNS:
-        if (!need(K * 8)) return fail(-1, "RETURNS needs K doubles");
-        return read_as_double(p, p->d_R, K, (double*)dst);
+        if (!need(P * K * 8)) return fail(-1, "RETURNS needs P*K doubles");
+        return read_as_double(p, p->d_R, P * K, (double*)dst);
     case MPPI_READ_ACT_SEQ:
-        if (!need(HM * 8)) return fail(-1, "ACT_SEQ needs H*M doubles");
-        HIP_OK(hipMemcpy(dst, p->d_base, HM * 8, hipMemcpyDeviceToHost));
+        if (!need(P * HM * 8)) return fail(-1, "ACT_SEQ needs P*H*M doubles");
+        HIP_OK(hipMemcpy(dst, p->d_base, P * HM * 8, hipMemcpyDeviceToHost));
         return 0;
-    case MPPI_READ_ARGMAX: {
-        if (!need(8)) return fail(-1, "ARGMAX needs one int64");
-        double r[2];
-        HIP_OK(hipMemcpy(r, p->d_result, 16, hipMemcpyDeviceToHost));
-        *(int64_t*)dst = (int64_t)r[1];
-        return 0;
-    }
+    case MPPI_READ_ARGMAX:
     case MPPI_READ_RMAX: {
-        if (!need(8)) return fail(-1, "RMAX needs one double");
-        double r[2];
-        HIP_OK(hipMemcpy(r, p->d_result, 16, hipMemcpyDeviceToHost));
-        *(double*)dst = r[0];
+        if (!need(P * 8)) return fail(-1, "ARGMAX / RMAX need P values");
+        std::vector<double> r(2 * P);
+        HIP_OK(hipMemcpy(r.data(), p->d_result, 16 * P, hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < P; b++) {
+            if (what == MPPI_READ_ARGMAX) ((int64_t*)dst)[b] = (int64_t)r[2 * b + 1];
+            else ((double*)dst)[b] = r[2 * b];
+        }
         return 0;
     }
     case MPPI_READ_ACTIONS: {
-        if (!need(K * HM * 8)) return fail(-1, "ACTIONS needs K*H*M doubles");
-        std::vector<double> e(HM * K), base(HM);
-        int rc = read_as_double(p, p->d_eps, HM * K, e.data());
+        if (!need(P * K * HM * 8)) return fail(-1, "ACTIONS needs P*K*H*M doubles");
+        std::vector<double> e(P * HM * K), base(P * HM);
+        int rc = read_as_double(p, p->d_eps, P * HM * K, e.data());
         if (rc) return rc;
-        HIP_OK(hipMemcpy(base.data(), p->d_base, HM * 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(base.data(), p->d_base, P * HM * 8, hipMemcpyDeviceToHost));
         double* o = (double*)dst;
-        for (size_t k = 0; k < K; k++)
-            for (size_t hm = 0; hm < HM; hm++) {
-                // same arithmetic as the kernel: the sum is formed in the rollout dtype
-                const double b = base[hm], x = e[hm * K + k];
-                double a;
-                if (p->explicit_act) a = x;
-                else if (p->cfg.dtype == MPPI_F32) a = (double)((float)b + (float)x);
-                else a = b + x;
-                o[k * HM + hm] = a;
-            }
+        for (size_t b = 0; b < P; b++)
+            for (size_t k = 0; k < K; k++)
+                for (size_t hm = 0; hm < HM; hm++) {
+                    // same arithmetic as the kernel: the sum is formed in the rollout dtype
+                    const double bb = base[b * HM + hm], x = e[(b * HM + hm) * K + k];
+                    double a;
+                    if (p->explicit_act) a = x;
+                    else if (p->cfg.dtype == MPPI_F32) a = (double)((float)bb + (float)x);
+                    else a = bb + x;
+                    o[(b * K + k) * HM + hm] = a;
+                }
         return 0;
     }
     case MPPI_READ_NEXT_OBS:
         if (!p->d_obs) return fail(-4, "planner was created without cfg.dump");
-        if (!need(K * H * OD * 8)) return fail(-1, "NEXT_OBS needs K*H*(2M+6) doubles");
-        return read_as_double(p, p->d_obs, K * H * OD, (double*)dst);
+        if (!need(P * K * H * OD * 8)) return fail(-1, "NEXT_OBS needs P*K*H*(2M+6) doubles");
+        return read_as_double(p, p->d_obs, P * K * H * OD, (double*)dst);
     case MPPI_READ_REWARDS:
         if (!p->d_rew) return fail(-4, "planner was created without cfg.dump");
-        if (!need(K * H * 8)) return fail(-1, "REWARDS needs K*H doubles");
-        return read_as_double(p, p->d_rew, K * H, (double*)dst);
+        if (!need(P * K * H * 8)) return fail(-1, "REWARDS needs P*K*H doubles");
+        return read_as_double(p, p->d_rew, P * K * H, (double*)dst);
     case MPPI_READ_STATUS:
         if (!need(4)) return fail(-1, "STATUS needs one int32");
         HIP_OK(hipMemcpy(dst, p->d_status, 4, hipMemcpyDeviceToHost));
         return 0;
     case MPPI_READ_PARTIALS:
-        if (!need((3 + HM) * 8)) return fail(-1, "PARTIALS needs 3+H*M doubles");
-        HIP_OK(hipMemcpy(dst, p->d_part, (3 + HM) * 8, hipMemcpyDeviceToHost));
+        if (!need(P * (3 + HM) * 8)) return fail(-1, "PARTIALS needs P*(3+H*M) doubles");
+        HIP_OK(hipMemcpy(dst, p->d_part, P * (3 + HM) * 8, hipMemcpyDeviceToHost));
         return 0;
     }
     return fail(-1, "unknown read selector");

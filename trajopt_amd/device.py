@@ -71,8 +71,11 @@ class DevicePlanner:
 
     def __init__(self, model: DeviceModel, K, H, kappa=1.0, gamma=1.0, sigma=None, betas=(1.0, 0.0, 0.0),
                  mean=None, default_act="repeat", reward_type="dense", dtype="f32", device=None, k_offset=0,
-                 dump=False):
+                 dump=False, planners=1):
+        """planners > 1 batches that many independent planners (own start state, base actions, noise
+        stream, log) in one handle: every per-planner array gains a leading axis of that size."""
         self.model, self.K, self.H, self.nv = model, int(K), int(H), model.nv
+        self.P = int(planners)
         self.dtype = dtype
         cfg = L.PlannerCfgC()
         cfg.K, cfg.H = self.K, self.H
@@ -81,6 +84,7 @@ class DevicePlanner:
         cfg.reward_type = L.REWARD_TYPES[reward_type]
         cfg.default_act = L.TAIL[default_act] if default_act in L.TAIL else L.TAIL["mean"]
         cfg.k_offset, cfg.dump = int(k_offset), int(bool(dump))
+        cfg.P = self.P
         cfg.kappa, cfg.gamma = float(kappa), float(gamma)
         sigma = np.ones(self.nv) if sigma is None else np.broadcast_to(np.asarray(sigma, float), (self.nv,))
         mean = np.zeros(self.nv) if mean is None else np.asarray(mean, float)
@@ -105,14 +109,18 @@ class DevicePlanner:
             pass
 
     # ---- inputs ---------------------------------------------------------------------
+    def _lead(self, *shape):
+        return shape if self.P == 1 else (self.P,) + shape
+
     def set_start_state(self, qpos, qvel, target, timestep=0):
         qpos, qvel, target = L.f64(qpos), L.f64(qvel), L.f64(target)
-        assert qpos.shape == (self.nv,) and qvel.shape == (self.nv,) and target.shape == (3,)
-        L.check(L.lib().mppi_set_start_state(self._h, L.ptr(qpos), L.ptr(qvel), L.ptr(target), int(timestep)))
+        ts = np.ascontiguousarray(np.broadcast_to(np.asarray(timestep, dtype=np.int32), (self.P,)))
+        assert qpos.shape == self._lead(self.nv) and qvel.shape == self._lead(self.nv) and target.shape == self._lead(3)
+        L.check(L.lib().mppi_set_start_state(self._h, L.ptr(qpos), L.ptr(qvel), L.ptr(target), L.ptr(ts)))
 
     def set_base_actions(self, act):
         act = L.f64(act)
-        assert act.shape == (self.H, self.nv), act.shape
+        assert act.shape == self._lead(self.H, self.nv), act.shape
         L.check(L.lib().mppi_set_base_actions(self._h, L.ptr(act)))
 
     def set_reference(self, reference, alpha=1.0):
@@ -125,7 +133,7 @@ class DevicePlanner:
 
     def upload_noise(self, raw):
         raw = L.f64(raw)
-        assert raw.shape == (self.K, self.H, self.nv), raw.shape
+        assert raw.shape == self._lead(self.K, self.H, self.nv), raw.shape
         L.check(L.lib().mppi_upload_noise(self._h, L.ptr(raw), None))
 
     def generate_noise(self, seed, stream=None):
@@ -139,19 +147,19 @@ class DevicePlanner:
         """Device-resident advance_time: real-env fp64 step with act_sequence[0], log, shift."""
         L.check(L.lib().mppi_advance(self._h, stream))
 
-    def read_log(self, max_rows=4096):
-        """Most recent rows of the real-env log, oldest first: dict of arrays + total count."""
+    def read_log(self, max_rows=4096, planner=0):
+        """Most recent rows of one planner's real-env log, oldest first: dict of arrays + total count."""
         nv = self.nv
         rows = np.empty((max_rows, 3 * nv + 7))
         n, total = C.c_int32(), C.c_int32()
-        L.check(L.lib().mppi_read_log(self._h, L.ptr(rows), int(max_rows), C.byref(n), C.byref(total)))
+        L.check(L.lib().mppi_read_log(self._h, int(planner), L.ptr(rows), int(max_rows), C.byref(n), C.byref(total)))
         r = rows[:n.value]
         return dict(qpos=r[:, :nv], qvel=r[:, nv:2 * nv], hand=r[:, 2 * nv:2 * nv + 3], target=r[:, 2 * nv + 3:2 * nv + 6],
                     reward=r[:, 2 * nv + 6], action=r[:, 2 * nv + 7:], total=total.value)
 
     def upload_actions(self, act):
         act = L.f64(act)
-        assert act.shape == (self.K, self.H, self.nv), act.shape
+        assert act.shape == self._lead(self.K, self.H, self.nv), act.shape
         L.check(L.lib().mppi_upload_actions(self._h, L.ptr(act), None))
 
     # ---- compute --------------------------------------------------------------------
@@ -205,28 +213,30 @@ class DevicePlanner:
         return out
 
     def returns(self):
-        return self._read(L.READ_RETURNS, (self.K,))
+        return self._read(L.READ_RETURNS, self._lead(self.K))
 
     def act_sequence(self):
-        return self._read(L.READ_ACT_SEQ, (self.H, self.nv))
+        return self._read(L.READ_ACT_SEQ, self._lead(self.H, self.nv))
 
     def argmax(self):
-        return int(self._read(L.READ_ARGMAX, (1,), np.int64)[0])
+        a = self._read(L.READ_ARGMAX, (self.P,), np.int64)
+        return int(a[0]) if self.P == 1 else a
 
     def rmax(self):
-        return float(self._read(L.READ_RMAX, (1,))[0])
+        a = self._read(L.READ_RMAX, (self.P,))
+        return float(a[0]) if self.P == 1 else a
 
     def actions(self):
-        return self._read(L.READ_ACTIONS, (self.K, self.H, self.nv))
+        return self._read(L.READ_ACTIONS, self._lead(self.K, self.H, self.nv))
 
     def next_observations(self):
-        return self._read(L.READ_NEXT_OBS, (self.K, self.H, 2 * self.nv + 6))
+        return self._read(L.READ_NEXT_OBS, self._lead(self.K, self.H, 2 * self.nv + 6))
 
     def rewards(self):
-        return self._read(L.READ_REWARDS, (self.K, self.H))
+        return self._read(L.READ_REWARDS, self._lead(self.K, self.H))
 
     def status(self):
         return int(self._read(L.READ_STATUS, (1,), np.int32)[0])
 
     def partials(self):
-        return self._read(L.READ_PARTIALS, (3 + self.H * self.nv,))
+        return self._read(L.READ_PARTIALS, self._lead(3 + self.H * self.nv))

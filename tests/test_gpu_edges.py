@@ -1,0 +1,123 @@
+"""Edge cases and full-size properties of the HIP path (GPU)."""
+import numpy as np
+import pytest
+
+from oracle import ref_mppi
+
+pytestmark = pytest.mark.gpu
+FILTER = [np.ones(7), 0.25, 0.8, 0.0]
+
+
+@pytest.fixture(scope="module")
+def dm():
+    from trajopt_amd.device import DeviceModel
+    return DeviceModel.get("reacher_7dof")
+
+
+def _p(dm, K, H, dtype="f32", **kw):
+    from trajopt_amd.device import DevicePlanner
+    kw.setdefault("kappa", 25.0)
+    kw.setdefault("sigma", FILTER[0])
+    kw.setdefault("betas", FILTER[1:])
+    return DevicePlanner(dm, K, H, dtype=dtype, **kw)
+
+
+@pytest.mark.parametrize("K,H", [(1, 1), (1, 2), (3, 5), (65, 3), (127, 16)])
+def test_ragged_and_tiny_shapes(dm, oracle_sim, K, H):
+    raw = ref_mppi.raw_normals(K + H, K, H, 7)
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)       # H < 3: nothing is filtered
+    base = np.full((H, 7), 0.1)
+    p = _p(dm, K, H, "f64", dump=True, default_act="repeat")
+    p.set_start_state(np.full(7, -0.2), np.zeros(7), np.zeros(3), 0)
+    p.set_base_actions(base)
+    p.upload_noise(raw)
+    p.iterate(1)
+    R_o, nobs_o, _ = oracle_sim.rollout(np.full(7, -0.2), np.zeros(7), np.zeros(3), 0, base + eps, dump=True)
+    assert np.abs(p.returns() - R_o).max() < 1e-10 and np.abs(p.next_observations() - nobs_o).max() < 1e-10
+    assert np.abs(p.act_sequence() - ref_mppi.update(base + eps, R_o, 25.0)).max() < 1e-10
+    assert p.argmax() == int(np.argmax(R_o))
+    if H > 1:
+        seq = p.act_sequence()
+        p.shift()
+        assert np.array_equal(p.act_sequence(), ref_mppi.shift(seq, "repeat", np.zeros(7)))
+    p.close()
+
+
+def test_bad_arguments_are_refused(dm):
+    from trajopt_amd._lib import MppiError
+    from trajopt_amd.device import DevicePlanner
+    for K, H in ((0, 4), (4, 0), (-1, 4)):
+        with pytest.raises(MppiError):
+            DevicePlanner(dm, K, H)
+    p = _p(dm, 8, 4)
+    with pytest.raises(AssertionError):
+        p.set_base_actions(np.zeros((5, 7)))
+    with pytest.raises(AssertionError):
+        p.upload_noise(np.zeros((8, 4, 6)))
+    p.upload_actions(np.zeros((8, 4, 7)))
+    with pytest.raises(MppiError):       # an update needs noise-relative samples
+        p.iterate(1)
+    with pytest.raises(MppiError):       # dumps were not requested
+        p.next_observations()
+    from trajopt_amd import _lib
+    assert _lib.lib().mppi_set_params(p._h, 1.0, 1.0, 9) != 0 and b"reward_type" in _lib.lib().mppi_last_error()
+    p.close()
+
+
+def test_full_size_rollouts_against_the_oracle(dm, oracle_sim):
+    """The benchmark configuration itself: K = 4096, H = 64, fp32, host-uploaded noise."""
+    K, H = 4096, 64
+    raw = ref_mppi.all_raw_normals(123, 512, 8, H, 7)           # 8 overlapping worker streams
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)
+    p = _p(dm, K, H, default_act="mean")
+    p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.upload_noise(raw)
+    p.iterate(1)
+    R = p.returns()
+    R_o = oracle_sim.rollout(np.zeros(7), np.zeros(7), np.zeros(3), 0, eps, nthreads=8)
+    rel = np.abs(R - R_o) / np.abs(R_o)
+    assert rel.max() < 1e-4, rel.max()                            # stated fp32 tolerance
+    assert p.argmax() == int(np.argmax(R_o)) == int(np.argmax(R))
+    assert p.status() == 0
+    # the update against the numpy restatement on the device's own returns
+    want = ref_mppi.update(eps.astype(np.float32).astype(np.float64), R, 25.0)
+    assert np.abs(p.act_sequence() - want).max() < 1e-6
+    # overlapping worker streams: worker i+1's stream is worker i's shifted by 512 seeds, not by 512 draws
+    assert np.array_equal(raw[512], ref_mppi.raw_normals(123 + 512, 1, H, 7)[0])
+    p.close()
+
+
+def test_size_independent_properties(dm):
+    K, H = 8192, 64
+    p = _p(dm, K, H, kappa=0.0)
+    p.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, 0.0, 0.0]), 0)
+    base = np.random.RandomState(0).randn(H, 7) * 0.1
+    p.set_base_actions(base)
+    p.generate_noise(11)
+    acts = p.actions()
+    p.iterate(1)
+    R1, seq1 = p.returns(), p.act_sequence()
+    # kappa = 0: every weight is 1, the update is the plain mean of the sampled actions
+    assert np.abs(seq1 - acts.sum(0) / (K + 1e-6)).max() < 1e-6
+    # bitwise reproducible: same state, same noise, same result
+    p.set_base_actions(base)
+    p.iterate(1)
+    assert np.array_equal(p.returns(), R1) and np.array_equal(p.act_sequence(), seq1)
+    # a return depends only on its own sample: shards of the same global stream reproduce their slice
+    s = _p(dm, 1024, H, kappa=0.0, k_offset=4096)
+    s.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, 0.0, 0.0]), 0)
+    s.set_base_actions(base)
+    s.generate_noise(11)
+    s.rollout()
+    assert np.array_equal(s.returns(), R1[4096:5120])
+    # discounting: gamma = 0 keeps only the first reward; all samples share state 0 but not action 0
+    p.set_params(0.0, 0.0, "dense")
+    p.set_base_actions(base)
+    p.rollout()
+    R0 = p.returns()
+    p.set_params(0.0, 1.0, "sparse")
+    p.rollout()
+    assert set(np.unique(p.returns() / H)).issubset({-10.0, -100.0, 100.0}) or np.all(p.returns() <= 100.0 * H)
+    assert np.all(R0 < 0) and R0.std() > 0
+    p.close(); s.close()

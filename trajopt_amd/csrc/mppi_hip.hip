@@ -635,6 +635,7 @@ struct mppi_planner {
     bool graph_valid;
     bool profiling;
     std::vector<hipEvent_t>* prof_events;   // start/stop pairs around every rollout launch
+    std::vector<DevState>* h_state;         // host mirror of the fields the host sets (alpha, ref_len, start state)
 };
 
 static hipStream_t pick(mppi_planner* p, void* s) { return s ? (hipStream_t)s : p->stream; }
@@ -716,6 +717,8 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     for (int j = 0; j < MPPI_MAXV; j++) p->fc.sigma[j] = cfg->sigma[j];
     p->fc.b0 = cfg->beta[0]; p->fc.b1 = cfg->beta[1]; p->fc.b2 = cfg->beta[2];
     p->prof_events = new std::vector<hipEvent_t>();
+    p->h_state = new std::vector<DevState>(P);
+    std::memset(p->h_state->data(), 0, sizeof(DevState) * P);
     *out = p;
     return 0;
 }
@@ -726,6 +729,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     (void)hipStreamSynchronize(p->stream);
     for (hipEvent_t e : *p->prof_events) (void)hipEventDestroy(e);
     delete p->prof_events;
+    delete p->h_state;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
                     p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count};
@@ -739,10 +743,8 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
                          const int32_t* timestep) {
     if (!p || !qpos || !qvel || !target3 || !timestep) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
-    // keep alpha / ref_len: fetch-modify-store through a host copy of the small structs
-    std::vector<DevState> s(p->P);
-    HIP_OK(hipMemcpyAsync(s.data(), p->d_state, sizeof(DevState) * p->P, hipMemcpyDeviceToHost, p->stream));
-    HIP_OK(hipStreamSynchronize(p->stream));
+    // alpha / ref_len come from the host mirror; q, v, target, timestep are replaced
+    std::vector<DevState>& s = *p->h_state;
     for (int b = 0; b < p->P; b++) {
         for (int i = 0; i < p->nv; i++) { s[b].q[i] = qpos[b * p->nv + i]; s[b].v[i] = qvel[b * p->nv + i]; }
         for (int c = 0; c < 3; c++) s[b].target[c] = target3[3 * b + c];
@@ -773,9 +775,13 @@ int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alp
         p->graph_valid = false;
     }
     if (T > 0) HIP_OK(hipMemcpy(p->d_ref, ref, (size_t)T * 3 * 8, hipMemcpyHostToDevice));
+    // the device copy of q / v / timestep may be ahead of the mirror (mppi_advance): patch only alpha and ref_len
     std::vector<DevState> s(p->P);
     HIP_OK(hipMemcpy(s.data(), p->d_state, sizeof(DevState) * p->P, hipMemcpyDeviceToHost));
-    for (auto& x : s) { x.alpha = alpha; x.ref_len = T; }
+    for (int b = 0; b < p->P; b++) {
+        s[b].alpha = alpha; s[b].ref_len = T;
+        (*p->h_state)[b].alpha = alpha; (*p->h_state)[b].ref_len = T;
+    }
     HIP_OK(hipMemcpy(p->d_state, s.data(), sizeof(DevState) * p->P, hipMemcpyHostToDevice));
     return 0;
 }

@@ -83,6 +83,19 @@ def flops_per_env_step():
     return total / n
 
 
+def measured_traffic():
+    """HBM bytes per rollout launch from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 corrections applied); None if the summary is not for this workload."""
+    path = os.path.join(ROOT, "profiles", "r1_final_rollout_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("K") == K_PER_GPU and d.get("H") == H:
+            return float(d["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,7 +195,7 @@ def main():
                                       % (world, 3 + H * M) if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "kernel": "rollout_kernel<float, Reacher7Dof>",
                          "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": measured_traffic(),
                          "flop_per_env_step": flops, "kernel_ms": k_ms, "launches": launches,
                          "hbm": {"algorithmic_bytes_per_launch": bytes_launch,
                                  "achieved_GBs": bytes_launch / (k_ms * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,

@@ -123,6 +123,13 @@ int mppi_set_base_actions(mppi_planner* p, const double* act_HxM);
  * ref may be NULL with T = 0. */
 int mppi_set_reference(mppi_planner* p, const double* ref_Tx3, int32_t T, double alpha);
 int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_type);
+/* Terminal-value critic of `MPPI.train_step(critic=...)` (trajopt/algos/mppi.py:134-159, 95-101;
+ * network trajopt/models/critic_nets.py:47-60): tanh MLP dim -> inner -> inner -> 1 in fp32, row-major
+ * weights as torch stores them (W1 [inner][dim], W2 [inner][inner], W3 [inner]).  While set, every
+ * rollout scores its last step with the critic's value of the final observation instead of the last
+ * reward.  dim selects the input slice (14, 15, 17, 3, 6); dim = 0 removes the critic.  inner must be 128. */
+int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1, const float* b1, const float* W2,
+                    const float* b2, const float* W3, float b3);
 
 /* Noise of `generate_perturbed_actions` (trajopt/utils.py:118-126).
  * upload: raw N(0,1) draws made on the host, sample-major (K,H,M) -- the exact-comparison

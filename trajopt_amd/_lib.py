@@ -59,6 +59,7 @@ _PROTOS = {
     "mppi_set_base_actions": (C.c_int, [_vp, _vp]),
     "mppi_set_reference": (C.c_int, [_vp, _vp, _i32, _d]),
     "mppi_set_params": (C.c_int, [_vp, _d, _d, _i32]),
+    "mppi_set_critic": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, C.c_float]),
     "mppi_upload_noise": (C.c_int, [_vp, _vp, _vp]),
     "mppi_generate_noise": (C.c_int, [_vp, _u64, _vp]),
     "mppi_generate_noise_step": (C.c_int, [_vp, _u64, _vp]),

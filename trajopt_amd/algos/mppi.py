@@ -23,6 +23,19 @@ from .trajopt_base import Trajectory
 _KERNEL_ENVS = {'reacher_7dof': 'reacher_7dof', 'continual_reacher_7dof': 'reacher_7dof'}
 
 
+def _critic_weights(critic, dim):
+    """(W1, b1, W2, b2, W3, b3) of a `Critic` whose terminal value has a device kernel, else None."""
+    from ..models.critic_nets import Critic
+    if type(critic) is not Critic or dim not in (14, 15, 17, 3, 6):
+        return None
+    w = [critic.linear1.weight, critic.linear1.bias, critic.linear2.weight, critic.linear2.bias,
+         critic.linear3.weight, critic.linear3.bias]
+    w = [x.detach().cpu().numpy().astype(np.float32) for x in w]
+    if w[0].shape != (128, dim) or w[2].shape != (128, 128) or w[4].shape != (1, 128):
+        return None
+    return w
+
+
 class MPPI(Trajectory):
     def __init__(self, env, H, paths_per_cpu,
                  num_cpu=1,
@@ -66,6 +79,7 @@ class MPPI(Trajectory):
         d = dict(self.__dict__)
         d.pop('_planner', None)
         d.pop('_planner_key', None)
+        d.pop('_critic_on', None)
         return d
 
     def __setstate__(self, d):
@@ -124,9 +138,11 @@ class MPPI(Trajectory):
 
     def train_step(self, critic=None, niter=1, act_sequence=None, goal=None, dim=14):
         t = len(self.sol_state) - 1
-        if critic is None and self.env.env_name in _KERNEL_ENVS:
-            self._plan_on_device(self.seed + t, niter)
+        weights = _critic_weights(critic, dim)
+        if self.env.env_name in _KERNEL_ENVS and (critic is None or weights is not None):
+            self._plan_on_device(self.seed + t, niter, dim if critic is not None else 0, weights)
         else:
+            # an arbitrary Python critic can only be evaluated on the host: rollouts come back as paths
             for _ in range(niter):
                 paths = self.do_rollouts(self.seed + t, goal=goal)
                 self._attach_critic_rewards(paths, critic, dim)
@@ -135,7 +151,7 @@ class MPPI(Trajectory):
         return []
 
     # ---- device-resident iteration ------------------------------------------------------
-    def _plan_on_device(self, seed, niter):
+    def _plan_on_device(self, seed, niter, critic_dim=0, critic_weights=None):
         s = self.sol_state[-1]
         H = self.H
         tracked = self.reward_type in ('tracking', 'cooling')
@@ -149,6 +165,9 @@ class MPPI(Trajectory):
         p.set_start_state(s['qp'], s['qv'], s['target_pos'], s['timestep'])
         p.set_reference(self.reference if tracked else None, self.env.alpha)
         p.set_base_actions(self.act_sequence)
+        if critic_dim or getattr(self, '_critic_on', False):
+            p.set_critic(critic_dim, critic_weights)
+            self._critic_on = bool(critic_dim)
         if self.noise == 'philox':
             p.generate_noise(seed)
         else:

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
 #include <climits>
 #include <cstdio>
 #include <cstring>
@@ -183,7 +184,8 @@ template <class T, class MD>
 __global__ void __launch_bounds__(RolloutBounds<T>::value)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
                const double* __restrict__ ref, int K, int H, int reward_type, double gamma, int explicit_act,
-               T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status) {
+               T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status,
+               T* __restrict__ fobs) {
     constexpr int NV = MD::NV;
     constexpr int OD = 2 * NV + 6;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,6 +195,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         st += pl; base += pl * H * NV; eps += pl * H * NV * K; R += pl * K;
         if (obs) obs += pl * K * H * OD;
         if (rew) rew += pl * K * H;
+        if (fobs) fobs += pl * K * OD;
     }
     T q[NV], v[NV];
     static_for<NV>([&](auto Ic) { q[Ic] = T(st->q[Ic]); v[Ic] = T(st->v[Ic]); });
@@ -227,8 +230,15 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         Vec3<T> hand;
         int ms = 0;
         const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_mask, ms);
-        ret += g * r;
+        // with a terminal-value critic the last reward is replaced by the critic's value (added by critic_kernel)
+        if (!(fobs && t == H - 1)) ret += g * r;
         g *= gm;
+        if (fobs && t == H - 1) {
+            T* o = fobs + (size_t)k * OD;
+            static_for<NV>([&](auto Ic) { o[Ic] = q[Ic]; o[NV + Ic] = v[Ic]; });
+            o[2 * NV + 0] = hand.v[0]; o[2 * NV + 1] = hand.v[1]; o[2 * NV + 2] = hand.v[2];
+            o[2 * NV + 3] = rp.target[0]; o[2 * NV + 4] = rp.target[1]; o[2 * NV + 5] = rp.target[2];
+        }
         if (rew) rew[(size_t)k * H + t] = r;
         if (obs) {
             T* o = obs + ((size_t)k * H + t) * OD;
@@ -339,6 +349,62 @@ __global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st,
 }
 
 // ------------------------------------------------------------------------------------------
+// terminal-value critic: tanh MLP in -> 128 -> 128 -> 1 on the final observation of every sample
+// (trajopt/models/critic_nets.py:47-60; input slices trajopt/algos/mppi.py:138-154), fp32 like the
+// reference's torch module.  One lane per sample; weights are wave-uniform (scalar loads).
+// R[k] += gamma^(H-1) * V(x_k): the rollout left the last reward out (trajopt/algos/mppi.py:97-101).
+// ------------------------------------------------------------------------------------------
+constexpr int CRITIC_INNER = 128;
+constexpr int CRITIC_IN = 17;          // widest input (qpos, qvel, goal); narrower inputs are zero padded
+
+template <class T, int NV>
+__global__ void __launch_bounds__(64) critic_kernel(const T* __restrict__ fobs, int K, int dim, const float* __restrict__ W1,
+                                                    const float* __restrict__ b1, const float* __restrict__ W2,
+                                                    const float* __restrict__ b2, const float* __restrict__ W3,
+                                                    double g_last, T* __restrict__ R) {
+    constexpr int OD = 2 * NV + 6;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    fobs += (size_t)blockIdx.y * K * OD;
+    R += (size_t)blockIdx.y * K;
+    const T* o = fobs + (size_t)k * OD;
+    float x[CRITIC_IN];
+#pragma unroll
+    for (int i = 0; i < CRITIC_IN; i++) x[i] = 0.f;
+    if (dim == 14 || dim == 15 || dim == 17) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) x[i] = (float)o[i];
+        if (dim == 15) {
+            const float dx = (float)o[OD - 6] - (float)o[OD - 3], dy = (float)o[OD - 5] - (float)o[OD - 2], dz = (float)o[OD - 4] - (float)o[OD - 1];
+            x[14] = sqrtf(dx * dx + dy * dy + dz * dz);
+        } else if (dim == 17) {
+            x[14] = (float)o[OD - 3]; x[15] = (float)o[OD - 2]; x[16] = (float)o[OD - 1];
+        }
+    } else if (dim == 3) {
+        x[0] = (float)o[OD - 6]; x[1] = (float)o[OD - 5]; x[2] = (float)o[OD - 4];
+    } else {  // 6
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = (float)o[OD - 6 + i];
+    }
+    float h1[CRITIC_INNER];
+#pragma unroll
+    for (int j = 0; j < CRITIC_INNER; j++) {
+        float a = b1[j];
+#pragma unroll
+        for (int i = 0; i < CRITIC_IN; i++) a = fmaf(W1[j * CRITIC_IN + i], x[i], a);
+        h1[j] = tanhf(a);
+    }
+    float out = W3[CRITIC_INNER];          // b3 follows W3 in the packed weight block
+    for (int j = 0; j < CRITIC_INNER; j++) {
+        float a = b2[j];
+#pragma unroll
+        for (int i = 0; i < CRITIC_INNER; i++) a = fmaf(W2[j * CRITIC_INNER + i], h1[i], a);
+        out = fmaf(W3[j], tanhf(a), out);
+    }
+    R[k] = R[k] + T(g_last) * T(out);
+}
+
+// ------------------------------------------------------------------------------------------
 // update kernels (fp64 accumulation, fixed reduction order -> bitwise reproducible)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void argmax_combine(double& v, int& i, double ov, int oi) {
@@ -404,6 +470,58 @@ __global__ void __launch_bounds__(256) wsum_kernel(const double* __restrict__ S,
     if (lane == 0) s_v[wave] = num;
     __syncthreads();
     if (tid == 0) part[3 + hm] = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
+}
+
+// Single-rank update in one launch: block (hm, planner) finds Rmax / first arg-max and sum S itself (every
+// block gets the same values, in the same fixed order), forms its weighted sum and writes act_sequence[hm].
+// Same arithmetic, in the same order, as weights_kernel + wsum_kernel + merge_kernel with one rank.
+template <class T>
+__global__ void __launch_bounds__(256) update_fused_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
+                                                          int k_offset, double* __restrict__ base, double* __restrict__ part,
+                                                          double* __restrict__ result) {
+    __shared__ double s_v[4];
+    __shared__ int s_i[4];
+    const int hm = blockIdx.x, HM = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + hm) * K;
+    base += (size_t)blockIdx.y * HM; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
+    // max / first arg-max: same 1024-strided partition as weights_kernel so ties resolve identically
+    double bv = -DBL_MAX;
+    int bi = INT_MAX;
+    for (int k = tid; k < K; k += 256) argmax_combine(bv, bi, (double)R[k], k);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = shfl_xor_d(bv, m);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    __syncthreads();
+    bv = s_v[0]; bi = s_i[0];
+    for (int w = 1; w < 4; w++) argmax_combine(bv, bi, s_v[w], s_i[w]);
+    __syncthreads();
+    double num = 0.0, den = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const double sk = exp(kappa * ((double)R[k] - bv));
+        num += sk * (double)eps[k];
+        den += sk;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { num += shfl_xor_d(num, m); den += shfl_xor_d(den, m); }
+    if (lane == 0) s_v[wave] = num;
+    __syncthreads();
+    const double n = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
+    __syncthreads();
+    if (lane == 0) s_v[wave] = den;
+    __syncthreads();
+    if (tid == 0) {
+        const double d = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
+        base[hm] = (base[hm] * d + n) / (d + 1e-6);
+        part[3 + hm] = n;
+        if (hm == 0) {
+            part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
+            result[0] = bv; result[1] = (double)(k_offset + bi);
+        }
+    }
 }
 
 // act_sequence = sum_k S_k (base + eps_k) / (sum S + 1e-6) from nranks shard statistics, rank order
@@ -480,7 +598,7 @@ __global__ void __launch_bounds__(256) update_direct_kernel(const double* __rest
 struct RolloutArgs {
     const DevState* st; const double* base; const void* eps; const double* ref;
     int K, H, P, reward_type; double gamma; int explicit_act;
-    void* R; void* obs; void* rew; int* status;
+    void* R; void* obs; void* rew; int* status; void* fobs;
 };
 
 struct ModelOps {
@@ -494,6 +612,7 @@ struct ModelOps {
     hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                           const double* mean, double* log, int log_cap, int* log_count, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
+    hipError_t (*critic)(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t);
 };
 
 static bool near(double a, double b) { return std::fabs(a - b) <= 1e-12 * (1.0 + std::fabs(b)); }
@@ -552,10 +671,10 @@ template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArg
     const dim3 grid((a.K + lanes - 1) / lanes, a.P), block(lanes);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((rollout_kernel<float, MD>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status);
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs);
     else
         hipLaunchKernelGGL((rollout_kernel<double, MD>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status);
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs);
     return hipGetLastError();
 }
 template <class MD>
@@ -590,9 +709,25 @@ static hipError_t launch_env_step(const double* in, int reward_type, int has_ref
     hipLaunchKernelGGL((env_step_kernel<MD>), dim3(1), dim3(64), 0, s, in, reward_type, has_ref, forward_only, out);
     return hipGetLastError();
 }
+// w: [W1 (128 x 17, zero padded) | b1 (128) | W2 (128 x 128) | b2 (128) | W3 (128) | b3 (1)]
+constexpr size_t CRITIC_W_FLOATS = CRITIC_INNER * CRITIC_IN + CRITIC_INNER + CRITIC_INNER * CRITIC_INNER + CRITIC_INNER + CRITIC_INNER + 1;
+template <class MD>
+static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t s) {
+    const float* W1 = w;
+    const float* b1 = W1 + CRITIC_INNER * CRITIC_IN;
+    const float* W2 = b1 + CRITIC_INNER;
+    const float* b2 = W2 + CRITIC_INNER * CRITIC_INNER;
+    const float* W3 = b2 + CRITIC_INNER;
+    const dim3 grid((K + 63) / 64, P), block(64);
+    if (dtype == MPPI_F32)
+        hipLaunchKernelGGL((critic_kernel<float, MD::NV>), grid, block, 0, s, (const float*)fobs, K, dim, W1, b1, W2, b2, W3, g_last, (float*)R);
+    else
+        hipLaunchKernelGGL((critic_kernel<double, MD::NV>), grid, block, 0, s, (const double*)fobs, K, dim, W1, b1, W2, b2, W3, g_last, (double*)R);
+    return hipGetLastError();
+}
 template <class MD> static ModelOps make_ops() {
     return {MD::name, MD::NV, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
-            &launch_advance<MD>, &launch_env_step<MD>};
+            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>};
 }
 static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>()};
 
@@ -627,6 +762,9 @@ struct mppi_planner {
     void* d_obs;           // T [K][H][2M+6]
     void* d_rew;           // T [K][H]
     int* d_status;
+    void* d_fobs;          // T [K][2M+6] final observation of every sample (critic input)
+    float* d_critic;       // packed critic weights (CRITIC_W_FLOATS) or null
+    int critic_dim;        // 0: no critic
     double* d_log;         // [LOG_CAP][3M+7] real-env log ring of mppi_advance
     int* d_log_count;
     int explicit_act;
@@ -732,7 +870,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     delete p->h_state;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
-                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count};
+                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     (void)hipStreamDestroy(p->stream);
@@ -783,6 +921,34 @@ int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alp
         (*p->h_state)[b].alpha = alpha; (*p->h_state)[b].ref_len = T;
     }
     HIP_OK(hipMemcpy(p->d_state, s.data(), sizeof(DevState) * p->P, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1, const float* b1, const float* W2,
+                    const float* b2, const float* W3, float b3) {
+    if (!p) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    p->graph_valid = false;
+    if (dim == 0) { p->critic_dim = 0; return 0; }
+    if (dim != 14 && dim != 15 && dim != 17 && dim != 3 && dim != 6) return fail(-1, "critic input dim must be 14, 15, 17, 3 or 6");
+    if (p->nv != 7) return fail(-1, "critic input slices are defined for the 20-dim reacher observation");
+    if (inner != CRITIC_INNER) return fail(-1, "only the 128-wide critic has a compiled kernel");
+    if (!W1 || !b1 || !W2 || !b2 || !W3) return fail(-1, "null critic weights");
+    std::vector<float> w(CRITIC_W_FLOATS, 0.f);
+    float* o = w.data();
+    for (int j = 0; j < CRITIC_INNER; j++)
+        for (int i = 0; i < dim; i++) o[j * CRITIC_IN + i] = W1[j * dim + i];
+    o += CRITIC_INNER * CRITIC_IN;
+    std::memcpy(o, b1, CRITIC_INNER * 4); o += CRITIC_INNER;
+    std::memcpy(o, W2, CRITIC_INNER * CRITIC_INNER * 4); o += CRITIC_INNER * CRITIC_INNER;
+    std::memcpy(o, b2, CRITIC_INNER * 4); o += CRITIC_INNER;
+    std::memcpy(o, W3, CRITIC_INNER * 4); o += CRITIC_INNER;
+    *o = b3;
+    if (!p->d_critic) HIP_OK(hipMalloc(&p->d_critic, CRITIC_W_FLOATS * 4));
+    if (!p->d_fobs) HIP_OK(hipMalloc(&p->d_fobs, (size_t)p->cfg.K * p->P * (2 * p->nv + 6) * p->esz));
+    HIP_OK(hipMemcpy(p->d_critic, w.data(), CRITIC_W_FLOATS * 4, hipMemcpyHostToDevice));
+    p->critic_dim = dim;
     return 0;
 }
 
@@ -871,12 +1037,16 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
     a.K = p->cfg.K; a.H = p->cfg.H; a.P = p->P; a.reward_type = p->cfg.reward_type; a.gamma = p->cfg.gamma;
     a.explicit_act = p->explicit_act;
     a.R = p->d_R; a.obs = p->d_obs; a.rew = p->d_rew; a.status = p->d_status;
+    a.fobs = p->critic_dim ? p->d_fobs : nullptr;
     HIP_OK(p->model->ops->rollout(p->cfg.dtype, a, s));
     if (p->profiling) {
         HIP_OK(hipEventRecord(e1, s));
         p->prof_events->push_back(e0);
         p->prof_events->push_back(e1);
     }
+    if (p->critic_dim)
+        HIP_OK(p->model->ops->critic(p->cfg.dtype, p->d_fobs, p->cfg.K, p->P, p->critic_dim, p->d_critic,
+                                     std::pow(p->cfg.gamma, (double)(p->cfg.H - 1)), p->d_R, s));
     return 0;
 }
 
@@ -890,6 +1060,17 @@ static int launch_partials(mppi_planner* p, hipStream_t s) {
                            p->cfg.k_offset, p->d_S, p->d_part);
         hipLaunchKernelGGL((wsum_kernel<double>), dim3(p->HM, p->P), dim3(256), 0, s, p->d_S, (const double*)p->d_eps, p->cfg.K, p->d_part);
     }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static int launch_update_fused(mppi_planner* p, hipStream_t s) {
+    if (p->cfg.dtype == MPPI_F32)
+        hipLaunchKernelGGL((update_fused_kernel<float>), dim3(p->HM, p->P), dim3(256), 0, s, (const float*)p->d_R, (const float*)p->d_eps,
+                           p->cfg.K, p->cfg.kappa, p->cfg.k_offset, p->d_base, p->d_part, p->d_result);
+    else
+        hipLaunchKernelGGL((update_fused_kernel<double>), dim3(p->HM, p->P), dim3(256), 0, s, (const double*)p->d_R, (const double*)p->d_eps,
+                           p->cfg.K, p->cfg.kappa, p->cfg.k_offset, p->d_base, p->d_part, p->d_result);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -935,8 +1116,7 @@ static int build_graph(mppi_planner* p) {
     hipGraph_t g;
     HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
     int rc = launch_rollout_only(p, p->stream);
-    if (!rc) rc = launch_partials(p, p->stream);
-    if (!rc) rc = launch_merge(p, p->d_part, 1, p->stream);
+    if (!rc) rc = launch_update_fused(p, p->stream);
     hipError_t e = hipStreamEndCapture(p->stream, &g);
     if (rc) return rc;
     HIP_OK(e);
@@ -959,8 +1139,7 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
     }
     for (int i = 0; i < niter; i++) {
         int rc = launch_rollout_only(p, s);
-        if (!rc) rc = launch_partials(p, s);
-        if (!rc) rc = launch_merge(p, p->d_part, 1, s);
+        if (!rc) rc = launch_update_fused(p, s);
         if (rc) return rc;
     }
     return 0;

@@ -131,6 +131,18 @@ class DevicePlanner:
     def set_params(self, kappa, gamma, reward_type):
         L.check(L.lib().mppi_set_params(self._h, float(kappa), float(gamma), L.REWARD_TYPES[reward_type]))
 
+    def set_critic(self, dim, weights=None):
+        """weights = (W1, b1, W2, b2, W3, b3) as float32 arrays in torch's row-major layout, or
+        None / dim 0 to remove the critic."""
+        if not dim or weights is None:
+            L.check(L.lib().mppi_set_critic(self._h, 0, 0, None, None, None, None, None, 0.0))
+            return
+        W1, b1, W2, b2, W3, b3 = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        inner = W2.shape[0]
+        assert W1.shape == (inner, dim) and W2.shape == (inner, inner) and W3.size == inner and b3.size == 1
+        L.check(L.lib().mppi_set_critic(self._h, int(dim), int(inner), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
+                                        L.ptr(W3), float(b3.reshape(-1)[0])))
+
     def upload_noise(self, raw):
         raw = L.f64(raw)
         assert raw.shape == self._lead(self.K, self.H, self.nv), raw.shape

@@ -143,11 +143,16 @@ def main():
         part = p.partials_tensor()
         gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
 
+    profiling = [True]        # kernel timing by HIP events needs individual launches (set False to replay a graph)
+
     def planning_step():
         # everything below is enqueued on one stream; there is no host synchronisation inside a step
+        if not sharded and not profiling[0]:
+            p.plan(SEED, 1, 1, sptr)                 # the same sequence as below, as one hipGraph replay
+            return
         p.generate_noise_step(SEED, sptr)            # Philox key = SEED + current timestep (read on the device)
         if not sharded:
-            p.iterate(1, sptr)                       # rollouts + weights + weighted sum + merge
+            p.iterate(1, sptr)                       # rollouts + fused update
         else:
             p.local_partials(sptr)
             dist.all_gather_into_tensor(gathered, part)

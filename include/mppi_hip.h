@@ -168,6 +168,11 @@ int mppi_shift(mppi_planner* p, const double* override_seq_HxM, void* stream);
  * (3M+7 doubles) to a ring of MPPI_LOG_CAP rows, and shifts the horizon.  No host round trip.
  * mppi_read_log copies the most recent rows (oldest first); total = rows ever written. */
 int mppi_advance(mppi_planner* p, void* stream);
+/* nsteps whole planning steps -- the loop `for t: agent.train_step(niter)` of the example scripts
+ * (sandbox/examples/reacher_7dof_mppi.py:49-50) -- enqueued as replays of one captured hipGraph:
+ * Philox noise keyed by seed + timestep, niter x (rollouts, update), device-resident advance.
+ * Nothing returns to the host until mppi_read_log / mppi_read. */
+int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream);
 int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
 
 int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);

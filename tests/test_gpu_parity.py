@@ -301,3 +301,25 @@ def test_constraint_free_arm(dtype):
         assert (np.abs(nobs - nobs_o) / (1 + np.abs(nobs_o))).max() < 1e-4
         assert (np.abs(R - R_o) / np.abs(R_o)).max() < 1e-4
     assert int(np.argmax(R)) == int(np.argmax(R_o))
+
+
+def test_whole_step_graph_equals_separate_calls(dev_model):
+    K, H, steps, niter = 128, 8, 6, 3
+    tgt = np.array([0.0, 0.05, 0.05])
+    a = _planner(dev_model, K, H, "f32")
+    b = _planner(dev_model, K, H, "f32")
+    for p in (a, b):
+        p.set_start_state(np.zeros(7), np.zeros(7), tgt, 0)
+        p.set_base_actions(np.zeros((H, 7)))
+    a.plan(91, niter=niter, nsteps=steps)
+    for _ in range(steps):
+        b.generate_noise_step(91)
+        b.iterate(niter)
+        b.advance()
+    la, lb = a.read_log(), b.read_log()
+    assert la["total"] == lb["total"] == steps
+    for key in ("qpos", "qvel", "hand", "reward", "action"):
+        assert np.array_equal(la[key], lb[key]), key
+    assert np.array_equal(a.act_sequence(), b.act_sequence())
+    a.plan(91, niter=niter, nsteps=2)              # replays the cached graph
+    assert a.read_log()["total"] == steps + 2

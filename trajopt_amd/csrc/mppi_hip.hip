@@ -771,6 +771,9 @@ struct mppi_planner {
     FilterCoefs fc;
     hipGraphExec_t graph;
     bool graph_valid;
+    hipGraphExec_t step_graph;      // whole planning step: noise -> niter x (rollout, update) -> advance
+    int step_graph_niter;
+    uint64_t step_graph_seed;
     bool profiling;
     std::vector<hipEvent_t>* prof_events;   // start/stop pairs around every rollout launch
     std::vector<DevState>* h_state;         // host mirror of the fields the host sets (alpha, ref_len, start state)
@@ -869,6 +872,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     delete p->prof_events;
     delete p->h_state;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
+    if (p->step_graph) (void)hipGraphExecDestroy(p->step_graph);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
                     p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic};
     for (void* b : bufs)
@@ -1142,6 +1146,49 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
         if (!rc) rc = launch_update_fused(p, s);
         if (rc) return rc;
     }
+    return 0;
+}
+
+// one whole planning step enqueued on s (no host synchronisation)
+static int enqueue_plan_step(mppi_planner* p, uint64_t seed, int niter, hipStream_t s) {
+    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->P, p->cfg.k_offset, seed, p->d_state, 1, p->fc,
+                                       p->d_eps, s));
+    for (int i = 0; i < niter; i++) {
+        int rc = launch_rollout_only(p, s);
+        if (!rc) rc = launch_update_fused(p, s);
+        if (rc) return rc;
+    }
+    HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
+                                  p->d_log, MPPI_LOG_CAP, p->d_log_count, s));
+    return 0;
+}
+
+int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream) {
+    if (!p || niter < 1 || nsteps < 0) return fail(-1, "bad argument");
+    if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_plan");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    hipStream_t s = pick(p, stream);
+    p->explicit_act = 0;
+    static const bool use_graph = [] { const char* e = getenv("MPPI_GRAPH"); return !(e && e[0] == '0'); }();
+    if (!use_graph || p->profiling) {
+        for (int i = 0; i < nsteps; i++) { int rc = enqueue_plan_step(p, seed, niter, s); if (rc) return rc; }
+        return 0;
+    }
+    if (!p->step_graph || !p->graph_valid || p->step_graph_niter != niter || p->step_graph_seed != seed) {
+        if (p->step_graph) { HIP_OK(hipGraphExecDestroy(p->step_graph)); p->step_graph = nullptr; }
+        hipGraph_t g;
+        HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_plan_step(p, seed, niter, p->stream);
+        const hipError_t e = hipStreamEndCapture(p->stream, &g);
+        if (rc) return rc;
+        HIP_OK(e);
+        HIP_OK(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
+        HIP_OK(hipGraphDestroy(g));
+        p->step_graph_niter = niter;
+        p->step_graph_seed = seed;
+        if (!p->graph_valid) { const int rc2 = build_graph(p); if (rc2) return rc2; }    // shares the validity flag
+    }
+    for (int i = 0; i < nsteps; i++) HIP_OK(hipGraphLaunch(p->step_graph, s));
     return 0;
 }
 

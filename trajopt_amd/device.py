@@ -159,6 +159,10 @@ class DevicePlanner:
         """Device-resident advance_time: real-env fp64 step with act_sequence[0], log, shift."""
         L.check(L.lib().mppi_advance(self._h, stream))
 
+    def plan(self, seed, niter=1, nsteps=1, stream=None):
+        """nsteps whole planning steps (noise, niter iterations, real-env step, shift) as graph replays."""
+        L.check(L.lib().mppi_plan(self._h, int(seed) & (2 ** 64 - 1), int(niter), int(nsteps), stream))
+
     def read_log(self, max_rows=4096, planner=0):
         """Most recent rows of one planner's real-env log, oldest first: dict of arrays + total count."""
         nv = self.nv

@@ -9,6 +9,7 @@ drawn (`np.random.seed(base_seed + i*paths_per_cpu)` per worker, `generate_paths
 """
 import random
 from collections import namedtuple
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -127,8 +128,32 @@ def _check_reference(reward_type, reference, timestep, H):
             raise IndexError("index %d is out of bounds for axis 0 with size %d" % (timestep + H, len(reference)))
 
 
+class _StatesView(Sequence):
+    """`states` of one path (trajopt/utils.py:89,98): H state dicts {qp, qv, target_pos, timestep},
+    materialised on access from the rollout's observation block instead of being built eagerly
+    for all K x H steps."""
+
+    def __init__(self, obs, target, t0, nv):
+        self._obs, self._target, self._t0, self._nv = obs, target, t0, nv
+
+    def __len__(self):
+        return self._obs.shape[0]
+
+    def __getitem__(self, t):
+        if isinstance(t, slice):
+            return [self[i] for i in range(*t.indices(len(self)))]
+        if t < 0:
+            t += len(self)
+        if not 0 <= t < len(self):
+            raise IndexError("list index out of range")
+        nv = self._nv
+        return dict(qp=self._obs[t, :nv].copy(), qv=self._obs[t, nv:2 * nv].copy(), target_pos=self._target.copy(),
+                    timestep=self._t0 + t)
+
+
 def _paths_from_device(p, start_state, act, env_name):
-    """Build the reference's list-of-dict `paths` (trajopt/utils.py:94-99) from device buffers."""
+    """Build the reference's list-of-dict `paths` (trajopt/utils.py:94-99) from device buffers.
+    Arrays are per-sample views of the K-sample blocks read back from the device."""
     K, H, nv = act.shape
     nobs = p.next_observations()                 # (K, H, 2nv+6): obs after every step
     rew = p.rewards()
@@ -140,17 +165,16 @@ def _paths_from_device(p, start_state, act, env_name):
     obs = np.concatenate([np.broadcast_to(obs0, (K, 1, obs0.size)), nobs[:, :-1]], axis=1)
     t0 = int(start_state['timestep'])
     timesteps = t0 + np.arange(H)
+    tp = np.broadcast_to(target, (H, 3))
     paths = []
     for k in range(K):
-        qp, qv = obs[k, :, :nv], obs[k, :, nv:2 * nv]
-        tp = np.broadcast_to(target, (H, 3)).copy()
-        states = [dict(qp=qp[t].copy(), qv=qv[t].copy(), target_pos=target.copy(), timestep=t0 + t) for t in range(H)]
-        paths.append(dict(observations=obs[k].copy(),
-                          actions=act[k].copy(),
-                          rewards=rew[k].copy(),
-                          env_infos=dict(state=dict(qp=qp.copy(), qv=qv.copy(), target_pos=tp, timestep=timesteps.copy())),
-                          states=states,
-                          next_observations=[nobs[k, t].copy() for t in range(H)]))
+        ok = obs[k]
+        paths.append(dict(observations=ok,
+                          actions=act[k],
+                          rewards=rew[k],
+                          env_infos=dict(state=dict(qp=ok[:, :nv], qv=ok[:, nv:2 * nv], target_pos=tp, timestep=timesteps)),
+                          states=_StatesView(ok, target, t0, nv),
+                          next_observations=list(nobs[k])))
     return paths
 
 

@@ -1,34 +1,51 @@
-"""Base class of the planners (trajopt/algos/trajopt_base.py:7-53)."""
+"""`Trajectory`: the planner base class callers may subclass
+(reference: trajopt/algos/trajopt_base.py:7-53).
+
+State kept by every planner: the env handle, the solution logs (`sol_state`, `sol_act`,
+`sol_reward`, `sol_obs`) and the open-loop `act_sequence` of shape (H, m).  The two
+`animate_*` methods replay logged states through the env; with the headless env of this
+package they only step it (its render hooks do nothing).
+"""
 import numpy as np
 
 
 class Trajectory:
     def __init__(self, env, H=32, seed=123):
-        self.env, self.seed = env, seed
-        self.n, self.m, self.H = env.observation_dim, env.action_dim, H
-        self.sol_state, self.sol_act, self.sol_reward, self.sol_obs = [], [], [], []
-        self.env.reset_model(seed=self.seed)
-        self.sol_state.append(self.env.get_env_state())
-        self.sol_obs.append(self.env._get_obs())
-        self.act_sequence = np.zeros((self.H, self.m))
+        self.env = env
+        self.seed = seed
+        self.H = H
+        self.n = env.observation_dim
+        self.m = env.action_dim
+        env.reset_model(seed=seed)
+        self.sol_state = [env.get_env_state()]
+        self.sol_obs = [env._get_obs()]
+        self.sol_act = []
+        self.sol_reward = []
+        self.act_sequence = np.zeros((H, self.m))
 
     def update(self, paths):
+        """Fold a set of rolled-out trajectories into `act_sequence`; planners implement it."""
         raise NotImplementedError
 
+    def _replay(self, first, actions, verbose):
+        # every step restarts from the logged state, exactly one env step per logged action
+        env = self.env
+        env.mujoco_render_frames = True
+        try:
+            for offset, action in enumerate(actions):
+                env.set_env_state(self.sol_state[first + offset])
+                env.step(action)
+                if verbose:
+                    print(env.env_timestep)
+                    print(env.real_step)
+        finally:
+            env.mujoco_render_frames = False
+
     def animate_rollout(self, t, act):
-        """Replay `act` from solution step t (headless: the env's render hooks are no-ops)."""
+        """Replay the action rows of `act` from solution step t."""
         self.env.set_env_state(self.sol_state[t])
-        self.env.mujoco_render_frames = True
-        for k in range(act.shape[0]):
-            self.env.set_env_state(self.sol_state[t + k])
-            self.env.step(act[k])
-            print(self.env.env_timestep)
-            print(self.env.real_step)
-        self.env.mujoco_render_frames = False
+        self._replay(t, list(act), verbose=True)
 
     def animate_result(self):
-        self.env.mujoco_render_frames = True
-        for k in range(len(self.sol_act)):
-            self.env.set_env_state(self.sol_state[k])
-            self.env.step(self.sol_act[k])
-        self.env.mujoco_render_frames = False
+        """Replay the whole logged solution."""
+        self._replay(0, self.sol_act, verbose=False)

@@ -1,19 +1,21 @@
-"""`ContinualReacher7DOFEnv` (trajopt/envs/continual_reacher_env.py:5-23): dense reward and a
-new target every 50 real steps."""
+"""`ContinualReacher7DOFEnv` (reference: trajopt/envs/continual_reacher_env.py:5-23): the dense-reward
+reacher whose target is redrawn after every 50th *real* step; rollout copies (`real_step` False)
+keep their target."""
 from .reacher_env import Reacher7DOFEnv
+
+RETARGET_PERIOD = 50
 
 
 class ContinualReacher7DOFEnv(Reacher7DOFEnv):
     def __init__(self):
-        super().__init__()
+        Reacher7DOFEnv.__init__(self)        # always the dense reward, no reference trajectory
         self.env_name = 'continual_reacher_7dof'
         self._ctor = {}
 
     def _step(self, a):
-        import numpy as np
-        reward = self._advance(np.asarray(a, dtype=np.float64), 'dense')
-        ob = self._get_obs()
-        self.env_timestep += 1
-        if self.env_timestep % 50 == 0 and self.env_timestep > 0 and self.real_step is True:
+        # the observation is taken before a possible target redraw, as in the reference
+        out = self._dense_step(a)
+        due = self.env_timestep > 0 and self.env_timestep % RETARGET_PERIOD == 0
+        if due and self.real_step is True:
             self.target_reset()
-        return ob, reward, False, self.get_env_infos()
+        return out

@@ -134,6 +134,13 @@ class Reacher7DOFEnv:
     def step(self, a):
         return self._step(a)
 
+    def _dense_step(self, a):
+        """One step with the dense reward whatever `reward_type` says; goal_dist is left untouched."""
+        reward = self._advance(np.asarray(a, dtype=np.float64), 'dense')
+        ob = self._get_obs()
+        self.env_timestep += 1
+        return ob, reward, False, self.get_env_infos()
+
     def _get_obs(self, goal_dist=False):
         parts = [self.data.qpos.flat, self.data.qvel.flat, self.data.site_xpos[self.hand_sid],
                  self.data.site_xpos[self.target_sid]]

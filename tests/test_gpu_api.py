@@ -269,3 +269,16 @@ def test_device_critic_equals_host_critic(oracle_sim, dim):
     p.set_critic(0)
     p.rollout()
     assert np.abs(p.returns() - (rew * 0.9 ** np.arange(H)).sum(1)).max() < 1e-3
+
+
+def test_example_script_flow():
+    """examples/reacher_goals.py: random goals, 116 steps, pickle round trip, sparse replay."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "reacher_goals.py")
+    spec = importlib.util.spec_from_file_location("reacher_goals", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    results = mod.main(["--steps", "116", "--seeds", "10", "13"])
+    for ret, hit, sparse, dt in results:
+        assert ret > -400.0 and sparse > -116 * 100.0
+    assert sum(r[1] for r in results) >= 1           # the hand gets within 2.5 cm of at least one of the goals

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define MPPI_MAXV 32
-#define MPPI_ABI_VERSION 1
+#define MPPI_ABI_VERSION 2
 #define MPPI_LOG_CAP 4096
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
@@ -41,7 +41,7 @@ enum {
     MPPI_READ_PARTIALS = 8      /* double[3+H*M]        this shard's (Rmax, argmax, den, num[H*M])      */
 };
 
-/* Flat model: links with hinge joints (welded bodies merged), the data the reference hands
+/* Flat model: one link per hinge or slide joint (welded bodies merged), the data the reference hands
  * to its simulator through `load_model_from_path` (trajopt/envs/mujoco_env.py:39-40). */
 typedef struct mppi_model_desc {
     char name[64];
@@ -74,6 +74,8 @@ typedef struct mppi_model_desc {
     double solref_k;
     double solref_b;
     double solimp[5];
+    double gravity[3];
+    int32_t jtype[MPPI_MAXV];   /* 0 hinge, 1 slide along `axis` */
 } mppi_model_desc;
 
 /* Planner configuration: the constructor arguments of `MPPI.__init__`

@@ -55,7 +55,9 @@ struct Model {               // mirrors trajopt_amd.model.ModelDesc (flat, row-m
     double solref_b;
     double solimp[5];
     double gravity[3];
+    int jtype[MAXV];           // 0 hinge, 1 slide (translation along `axis`)
 };
+constexpr int JOINT_SLIDE = 1;
 
 template <class S> struct V3 { S x, y, z; };
 template <class S> inline V3<S> operator+(V3<S> a, V3<S> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -105,10 +107,16 @@ template <class S> void forward_kinematics(const Model& md, const S* q, Kin<S>& 
             pp = k.p[pi];
         }
         V3<S> off = {S(md.pos[i][0]), S(md.pos[i][1]), S(md.pos[i][2])};
+        S ax = S(md.axis[i][0]), ay = S(md.axis[i][1]), az = S(md.axis[i][2]);
+        if (md.jtype[i] == JOINT_SLIDE) {
+            k.p[i] = pp + mul(Rp, off + q[i] * V3<S>{ax, ay, az});
+            k.R[i] = Rp;
+            k.a[i] = mul(Rp, V3<S>{ax, ay, az});
+            continue;
+        }
         k.p[i] = pp + mul(Rp, off);
         // Rodrigues rotation about the link-frame axis
         S s = sin(q[i]), c = cos(q[i]);
-        S ax = S(md.axis[i][0]), ay = S(md.axis[i][1]), az = S(md.axis[i][2]);
         S t = S(1.0) - c;
         M3<S> Rj;
         Rj.m[0][0] = c + t * ax * ax;      Rj.m[0][1] = t * ax * ay - s * az; Rj.m[0][2] = t * ax * az + s * ay;
@@ -166,8 +174,13 @@ template <class S> void inertia_and_bias(const Model& md, const Kin<S>& k, const
         I[i].I[3] = Iw.m[0][1] - m * c.x * c.y;
         I[i].I[4] = Iw.m[0][2] - m * c.x * c.z;
         I[i].I[5] = Iw.m[1][2] - m * c.y * c.z;
-        Sx[i].w = k.a[i];
-        Sx[i].v = cross(k.p[i], k.a[i]);
+        if (md.jtype[i] == JOINT_SLIDE) {
+            Sx[i].w = {S(0.0), S(0.0), S(0.0)};
+            Sx[i].v = k.a[i];
+        } else {
+            Sx[i].w = k.a[i];
+            Sx[i].v = cross(k.p[i], k.a[i]);
+        }
     }
     // recursive Newton-Euler with zero joint acceleration
     for (int i = 0; i < nv; i++) {

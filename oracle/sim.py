@@ -22,7 +22,7 @@ class CModel(C.Structure):
         ("dof_invweight", _d * MAXV), ("contact_pos", _d * 3), ("contact_radius", _d),
         ("contact_plane_z", _d), ("contact_margin", _d), ("contact_invweight", _d),
         ("hand_pos", _d * 3), ("solref_k", _d), ("solref_b", _d), ("solimp", _d * 5),
-        ("gravity", _d * 3),
+        ("gravity", _d * 3), ("jtype", _i * MAXV),
     ]
 
 
@@ -46,7 +46,7 @@ def to_cmodel(md) -> CModel:
     m.nv, m.frame_skip, m.h = md.nv, md.frame_skip, md.h
     m.contact_link, m.hand_link = md.contact_link, md.hand_link
     for i in range(md.nv):
-        m.parent[i] = int(md.parent[i]); m.limited[i] = int(md.limited[i])
+        m.parent[i] = int(md.parent[i]); m.limited[i] = int(md.limited[i]); m.jtype[i] = int(md.jtype[i])
         for c in range(3):
             m.pos[i][c] = md.pos[i][c]; m.axis[i][c] = md.axis[i][c]; m.com[i][c] = md.com[i][c]
         for c in range(6):
@@ -55,7 +55,7 @@ def to_cmodel(md) -> CModel:
                   "ctrl_hi", "dof_invweight"):
             getattr(m, f)[i] = float(getattr(md, f)[i])
     for c in range(3):
-        m.contact_pos[c] = md.contact_pos[c]; m.hand_pos[c] = md.hand_pos[c]; m.gravity[c] = 0.0
+        m.contact_pos[c] = md.contact_pos[c]; m.hand_pos[c] = md.hand_pos[c]; m.gravity[c] = float(md.gravity[c])
     m.contact_radius, m.contact_plane_z = md.contact_radius, md.contact_plane_z
     m.contact_margin, m.contact_invweight = md.contact_margin, md.contact_invweight
     m.solref_k, m.solref_b = md.solref_k, md.solref_b

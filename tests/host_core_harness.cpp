@@ -39,5 +39,6 @@ extern "C" void core_rollout(int f64, int model, const double* q0, const double*
                              double* ret, int* sweeps) {
 #define GO(T, MD) run<T, MD>(q0, v0, target, act, H, reward_type, ref, t0, alpha, gamma, q_out, v_out, hand_out, rewards, ret, sweeps)
     if (model == 0) { if (f64) GO(double, Reacher7Dof); else GO(float, Reacher7Dof); }
-    else            { if (f64) GO(double, Reacher7DofFree); else GO(float, Reacher7DofFree); }
+    else if (model == 1) { if (f64) GO(double, Reacher7DofFree); else GO(float, Reacher7DofFree); }
+    else                 { if (f64) GO(double, Tree18Dof); else GO(float, Tree18Dof); }
 }

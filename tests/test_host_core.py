@@ -24,7 +24,8 @@ def core():
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         q0, v0, tgt, act = (np.ascontiguousarray(x, dtype=np.float64) for x in (q0, v0, tgt, act))
         H = act.shape[0]
-        q, v, hand, rew = np.zeros(7), np.zeros(7), np.zeros(3), np.zeros(H)
+        nv = act.shape[1]
+        q, v, hand, rew = np.zeros(nv), np.zeros(nv), np.zeros(3), np.zeros(H)
         R, sw = C.c_double(), C.c_int()
         refp = None if ref is None else p(np.ascontiguousarray(ref, dtype=np.float64))
         L.core_rollout(int(f64), model, p(q0), p(v0), p(tgt), p(act), H, rt, refp, t0, C.c_double(alpha),
@@ -80,3 +81,24 @@ def test_reward_types_and_free_model(core, oracle_sim):
     R_o, nobs_o, _ = free.rollout(q0, v0, tgt, 0, act[None] * 3, dump=True)
     q, v, _, _, R, sw = core(1, q0, v0, tgt, act * 3, model=1)
     assert sw == 0 and np.abs(q - nobs_o[0, -1, :7]).max() < 1e-10 and abs(R - R_o[0]) < 1e-10
+
+
+def test_tree_model_slides_and_gravity(core):
+    """18-DoF floating-base tree (slides, branching, gravity): the link-local kernel arithmetic
+    against the world-frame oracle, whose bias forces are themselves checked against a finite-
+    difference Lagrangian in test_oracle_tree.py."""
+    from oracle.sim import OracleSim
+    from trajopt_amd.model import get_model
+    sim = OracleSim(get_model("tree_18dof"))
+    rs = np.random.RandomState(11)
+    H = 64
+    q0, v0, tgt = rs.randn(18) * 0.4, rs.randn(18) * 0.5, np.array([0.3, 0.1, 1.0])
+    act = rs.randn(H, 18)
+    R_o, nobs_o, rew_o = sim.rollout(q0, v0, tgt, 0, act[None], gamma=0.99, dump=True)
+    q, v, hand, rew, R, sw = core(1, q0, v0, tgt, act, gamma=0.99, model=2)
+    assert sw == 0
+    assert np.abs(q - nobs_o[0, -1, :18]).max() < 1e-9 and np.abs(v - nobs_o[0, -1, 18:36]).max() < 1e-9
+    assert np.abs(rew - rew_o[0]).max() < 1e-9 and abs(R - R_o[0]) < 1e-8
+    assert np.abs(hand - nobs_o[0, -1, 36:39]).max() < 1e-10
+    q, v, _, _, R32, _ = core(0, q0, v0, tgt, act, gamma=0.99, model=2)
+    assert (np.abs(np.r_[q, v] - nobs_o[0, -1, :36]) / (1 + np.abs(nobs_o[0, -1, :36]))).max() < 2e-3

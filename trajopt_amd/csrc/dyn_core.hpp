@@ -131,6 +131,12 @@ template <class T, class MD> struct Step {
     };
 
     template <int I> static MPPI_HD Vec3<T> pos_() { return {{T(MD::pos[I][0]), T(MD::pos[I][1]), T(MD::pos[I][2])}}; }
+    // origin of link I in its parent's frame: constant for a hinge, displaced along the axis by q for a slide
+    template <int I> static MPPI_HD Vec3<T> off_(const T (&q)[NV]) {
+        Vec3<T> r = pos_<I>();
+        if constexpr (MD::jtype[I] == 1) r.v[MD::axis_id[I]] += T(MD::axis_sign[I]) * q[I];
+        return r;
+    }
     template <int I> static MPPI_HD Vec3<T> mc_() { return {{T(MD::mc[I][0]), T(MD::mc[I][1]), T(MD::mc[I][2])}}; }
 
     // true if link a is link l or one of its ancestors
@@ -145,10 +151,11 @@ template <class T, class MD> struct Step {
     // coordinates of a point fixed in link I, expressed in every ancestor frame on the way to the
     // world: x[i] = point in link-i coordinates, returns world coordinates
     template <int I>
-    static MPPI_HD Vec3<T> point_to_world(const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& x, Vec3<T> (&xs)[NV]) {
+    static MPPI_HD Vec3<T> point_to_world(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& x,
+                                          Vec3<T> (&xs)[NV]) {
         xs[I] = x;
-        const Vec3<T> xp = add(pos_<I>(), to_parent<MD::axis_id[I]>(cs[I], sn[I], x));
-        if constexpr (MD::parent[I] >= 0) return point_to_world<MD::parent[I]>(cs, sn, xp, xs);
+        const Vec3<T> xp = add(off_<I>(q), to_parent<MD::axis_id[I]>(cs[I], sn[I], x));
+        if constexpr (MD::parent[I] >= 0) return point_to_world<MD::parent[I]>(q, cs, sn, xp, xs);
         else return xp;
     }
 
@@ -163,24 +170,28 @@ template <class T, class MD> struct Step {
         T cs[NV], sn[NV];
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
-            T s, c;
-            sincos_t(q[i], s, c);
-            cs[i] = c;
-            sn[i] = (MD::axis_sign[i] > 0) ? s : -s;
+            if constexpr (MD::jtype[i] == 1) {
+                cs[i] = T(1); sn[i] = T(0);          // a slide does not turn its frame
+            } else {
+                T s, c;
+                sincos_t(q[i], s, c);
+                cs[i] = c;
+                sn[i] = (MD::axis_sign[i] > 0) ? s : -s;
+            }
         });
 
         // ---- points of interest in world coordinates ----------------------------------------
         if constexpr (MD::hand_link >= 0) {
             if (want_hand) {
                 Vec3<T> tmp[NV];
-                out.hand = point_to_world<MD::hand_link>(cs, sn, {{T(MD::hand_pos[0]), T(MD::hand_pos[1]), T(MD::hand_pos[2])}}, tmp);
+                out.hand = point_to_world<MD::hand_link>(q, cs, sn, {{T(MD::hand_pos[0]), T(MD::hand_pos[1]), T(MD::hand_pos[2])}}, tmp);
             }
         }
 
         T bias[NV];
-        bias_forces(cs, sn, qd, bias);
+        bias_forces(q, cs, sn, qd, bias);
         T M[NV][NV];     // lower triangle used: M[i][j], i >= j
-        mass_matrix(cs, sn, M);
+        mass_matrix(q, cs, sn, M);
 
         // ---- smooth force -------------------------------------------------------------------
         T fs[NV];
@@ -221,7 +232,7 @@ template <class T, class MD> struct Step {
         if constexpr (MD::contact_link >= 0) {
             constexpr int L = MD::contact_link;
             Vec3<T> xc[NV];
-            const Vec3<T> cw = point_to_world<L>(cs, sn, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
+            const Vec3<T> cw = point_to_world<L>(q, cs, sn, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
             const T dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
             if (dist < T(MD::contact_margin)) {
                 // d(z of the sphere centre)/dq_i = z_i . (axis_i x x_i): world z axis and the point, both in link-i coordinates
@@ -230,6 +241,7 @@ template <class T, class MD> struct Step {
                 static_for<NV>([&](auto Ic) {
                     constexpr int i = Ic;
                     if constexpr (on_path(i, L)) {
+                        static_assert(MD::jtype[i] == 0, "the contact row is written for hinge chains");
                         constexpr int p = MD::parent[i];
                         constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
                         Vec3<T> zp;
@@ -322,29 +334,37 @@ template <class T, class MD> struct Step {
     }
 
     // bias forces: recursive Newton-Euler with zero joint acceleration, link-local coordinates
-    static MPPI_HD void bias_forces(const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], T (&bias)[NV]) {
+    static MPPI_HD void bias_forces(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], T (&bias)[NV]) {
         Vec3<T> om[NV], vl[NV], al[NV], ac[NV];       // angular/linear velocity, angular/linear spatial accel
         Vec3<T> fn[NV], ff[NV];                       // moment about link origin, force
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             constexpr int p = MD::parent[i];
             constexpr int A = MD::axis_id[i];
-            const Vec3<T> r = pos_<i>();
+            const Vec3<T> r = off_<i>(q);
             Vec3<T> w, v, a_w, a_v;
             if constexpr (p < 0) {
                 w = {{T(0), T(0), T(0)}}; v = w; a_w = w; a_v = w;
+                // gravity enters as an upward acceleration of the world
+                if constexpr (MD::has_gravity)
+                    a_v = to_child<A>(cs[i], sn[i], Vec3<T>{{T(-MD::gravity[0]), T(-MD::gravity[1]), T(-MD::gravity[2])}});
             } else {
                 w = to_child<A>(cs[i], sn[i], om[p]);
                 v = to_child<A>(cs[i], sn[i], add(vl[p], cross(om[p], r)));
                 a_w = to_child<A>(cs[i], sn[i], al[p]);
                 a_v = to_child<A>(cs[i], sn[i], add(ac[p], cross(al[p], r)));
             }
-            // joint rate about axis A; velocity-product acceleration V x (S qd)
+            // joint rate along / about axis A; velocity-product acceleration V x (S qd)
             Vec3<T> sq = {{T(0), T(0), T(0)}};
             sq.v[A] = T(MD::axis_sign[i]) * qd[i];
-            a_w = add(a_w, cross(w, sq));
-            a_v = add(a_v, cross(v, sq));
-            w.v[A] += sq.v[A];
+            if constexpr (MD::jtype[i] == 1) {
+                a_v = add(a_v, cross(w, sq));
+                v.v[A] += sq.v[A];
+            } else {
+                a_w = add(a_w, cross(w, sq));
+                a_v = add(a_v, cross(v, sq));
+                w.v[A] += sq.v[A];
+            }
             om[i] = w; vl[i] = v; al[i] = a_w; ac[i] = a_v;
             const T m = T(MD::mass[i]);
             const Vec3<T> h = mc_<i>();
@@ -360,9 +380,9 @@ template <class T, class MD> struct Step {
             constexpr int i = NV - 1 - Ic;
             constexpr int p = MD::parent[i];
             constexpr int A = MD::axis_id[i];
-            bias[i] = T(MD::axis_sign[i]) * fn[i].v[A];
+            bias[i] = T(MD::axis_sign[i]) * (MD::jtype[i] == 1 ? ff[i].v[A] : fn[i].v[A]);
             if constexpr (p >= 0) {
-                const Vec3<T> r = pos_<i>();
+                const Vec3<T> r = off_<i>(q);
                 const Vec3<T> f = to_parent<A>(cs[i], sn[i], ff[i]);
                 const Vec3<T> n = to_parent<A>(cs[i], sn[i], fn[i]);
                 ff[p] = add(ff[p], f);
@@ -373,8 +393,14 @@ template <class T, class MD> struct Step {
     }
 
     // joint-space inertia (lower triangle, armature included): composite rigid bodies in link coordinates
-    static MPPI_HD void mass_matrix(const T (&cs)[NV], const T (&sn)[NV], T (&M)[NV][NV]) {
+    static MPPI_HD void mass_matrix(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], T (&M)[NV][NV]) {
         SpInertia<T> Ic_[NV];
+        // joints on different branches do not couple
+        static_for<NV>([&](auto In) {
+            static_for<In>([&](auto Jn) {
+                if constexpr (!on_path(Jn, In)) M[In][Jn] = T(0);
+            });
+        });
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             Ic_[i].m = T(MD::mass[i]);
@@ -390,10 +416,17 @@ template <class T, class MD> struct Step {
                 Vec3<T> ea = {{T(0), T(0), T(0)}};
                 constexpr T sgn = T(MD::axis_sign[i]);
                 ea.v[A] = sgn;
-                Vec3<T> n = {{sgn * Ic_[i].I[sym_idx(0, A)], sgn * Ic_[i].I[sym_idx(1, A)], sgn * Ic_[i].I[sym_idx(2, A)]}};
-                Vec3<T> f = cross(ea, Ic_[i].h);
-                M[i][i] = Ic_[i].I[sym_idx(A, A)] + T(MD::armature[i]);
-                walk_up<i, i>(cs, sn, n, f, M);
+                if constexpr (MD::jtype[i] == 1) {
+                    const Vec3<T> n = cross(Ic_[i].h, ea);
+                    const Vec3<T> f = scale(Ic_[i].m, ea);
+                    M[i][i] = Ic_[i].m + T(MD::armature[i]);
+                    walk_up<i, i>(q, cs, sn, n, f, M);
+                } else {
+                    Vec3<T> n = {{sgn * Ic_[i].I[sym_idx(0, A)], sgn * Ic_[i].I[sym_idx(1, A)], sgn * Ic_[i].I[sym_idx(2, A)]}};
+                    Vec3<T> f = cross(ea, Ic_[i].h);
+                    M[i][i] = Ic_[i].I[sym_idx(A, A)] + T(MD::armature[i]);
+                    walk_up<i, i>(q, cs, sn, n, f, M);
+                }
             }
             if constexpr (p >= 0) {
                 // express composite i in the parent frame and add it to the parent's composite
@@ -410,7 +443,7 @@ template <class T, class MD> struct Step {
                 J[sym_idx(U, U)] = cc * Iuu - T(2) * sc * Iuw + ss * Iww;
                 J[sym_idx(W, W)] = ss * Iuu + T(2) * sc * Iuw + cc * Iww;
                 J[sym_idx(U, W)] = sc * (Iuu - Iww) + (cc - ss) * Iuw;
-                const Vec3<T> r = pos_<i>();
+                const Vec3<T> r = off_<i>(q);
                 const T m = Ic_[i].m;
                 const T rr = r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2];
                 const T rh = r.v[0] * h.v[0] + r.v[1] * h.v[1] + r.v[2] * h.v[2];
@@ -431,15 +464,16 @@ template <class T, class MD> struct Step {
 
     // carry the force (n about origin of link I, f) of column COL up the tree, filling M[COL][ancestor]
     template <int COL, int I>
-    static MPPI_HD void walk_up(const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& n, const Vec3<T>& f, T (&M)[NV][NV]) {
+    static MPPI_HD void walk_up(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& n, const Vec3<T>& f,
+                                T (&M)[NV][NV]) {
         constexpr int p = MD::parent[I];
         if constexpr (p >= 0) {
             constexpr int A = MD::axis_id[I];
-            const Vec3<T> r = pos_<I>();
+            const Vec3<T> r = off_<I>(q);
             const Vec3<T> fp = to_parent<A>(cs[I], sn[I], f);
             const Vec3<T> np = add(to_parent<A>(cs[I], sn[I], n), cross(r, fp));
-            M[COL][p] = T(MD::axis_sign[p]) * np.v[MD::axis_id[p]];
-            walk_up<COL, p>(cs, sn, np, fp, M);
+            M[COL][p] = T(MD::axis_sign[p]) * (MD::jtype[p] == 1 ? fp.v[MD::axis_id[p]] : np.v[MD::axis_id[p]]);
+            walk_up<COL, p>(q, cs, sn, np, fp, M);
         }
     }
 

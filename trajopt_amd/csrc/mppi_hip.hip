@@ -628,6 +628,7 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
     CHK(d->hand_link == MD::hand_link, "hand_link");
     for (int i = 0; i < NV; i++) {
         CHK(d->parent[i] == MD::parent[i], "parent");
+        CHK(d->jtype[i] == MD::jtype[i], "joint type");
         CHK((d->limited[i] != 0) == (MD::limited[i] != 0), "limited");
         const double m = d->mass[i];
         for (int c = 0; c < 3; c++) {
@@ -660,6 +661,7 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
         CHK(near(d->contact_invweight, MD::contact_invweight), "contact_invweight");
     }
     for (int c = 0; c < 3; c++) CHK(near(d->hand_pos[c], MD::hand_pos[c]), "hand_pos");
+    for (int c = 0; c < 3; c++) CHK(near(d->gravity[c], MD::gravity[c]), "gravity");
     CHK(near(d->solref_k, MD::solref_k) && near(d->solref_b, MD::solref_b), "solref");
     for (int c = 0; c < 5; c++) CHK(near(d->solimp[c], MD::solimp[c]), "solimp");
 #undef CHK
@@ -729,7 +731,7 @@ template <class MD> static ModelOps make_ops() {
     return {MD::name, MD::NV, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
             &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>};
 }
-static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>()};
+static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>()};
 
 // ------------------------------------------------------------------------------------------
 // handles

@@ -7,9 +7,10 @@ derived from the geoms, soft-constraint constants) that is (a) passed through
 the C ABI (``mppi_model_desc`` in ``include/mppi_hip.h``) and (b) baked into
 the HIP kernels as compile-time constants by ``tools/gen_model_header.py``.
 
-Only the subset of the model language that ``reacher_7dof`` uses is covered:
-bodies without orientation offsets, hinge joints at the body origin, sphere /
-capsule / plane geoms, sites, motors with gear and ctrlrange, Euler integrator.
+Covered subset of the model language: bodies without orientation offsets, hinge
+and slide joints at the body origin (several per body compose in order, which is
+how a floating base is written: three slides then three hinges), sphere / capsule /
+plane geoms, sites, motors with gear and ctrlrange, gravity, Euler integrator.
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -17,6 +18,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 DENSITY = 1000.0  # default geom density
+HINGE, SLIDE = 0, 1
 
 
 # --------------------------------------------------------------------------
@@ -41,6 +43,7 @@ class Joint:
     limited: bool = True
     gear: float = 10.0
     ctrlrange: Tuple[float, float] = (-1.0, 1.0)
+    kind: str = "hinge"                         # 'hinge' | 'slide'
 
 
 @dataclass
@@ -51,6 +54,12 @@ class Body:
     geoms: List[Geom] = field(default_factory=list)
     sites: dict = field(default_factory=dict)          # name -> local pos
     children: List["Body"] = field(default_factory=list)
+    joints: Optional[List[Joint]] = None               # several joints on one body, applied in order
+
+    def joint_list(self):
+        if self.joints:
+            return list(self.joints)
+        return [] if self.joint is None else [self.joint]
 
 
 @dataclass
@@ -106,6 +115,35 @@ def reacher_7dof_spec() -> ModelSpec:
     return ModelSpec("reacher_7dof", 0.01, 2, [pan], plane_z=-0.425)                       # plane :11
 
 
+def tree_18dof_spec() -> ModelSpec:
+    """Synthetic 18-DoF tree for precision and scaling studies: a floating trunk (three slides
+    along x, y, z, then three hinges about x, y, z) carrying four limbs of three hinges each.
+    Gravity on, no joint limits, no collisions, frame_skip 1.  Not a model of the reference;
+    the end-effector site `finger` is the tip of the first limb."""
+    free = dict(limited=False, range=(0.0, 0.0))
+
+    def limb(tag, root_pos, out):
+        # out: unit direction of the limb in the trunk frame (+-x or +-y)
+        o = np.asarray(out, float)
+        side = (0.0, 1.0, 0.0) if abs(o[0]) > 0 else (1.0, 0.0, 0.0)
+        seg = lambda L, r: Geom("capsule", r, fromto=(0, 0, 0) + tuple(L * o))
+        tip = Body(tag + "_wrist", tuple(0.25 * o), Joint(tuple(abs(o)), damping=0.2, armature=0.01, gear=4.0, **free),
+                   [seg(0.12, 0.025)], {"finger": tuple(0.12 * o)} if tag == "limb0" else {})
+        mid = Body(tag + "_elbow", tuple(0.3 * o), Joint(side, damping=0.3, armature=0.01, gear=6.0, **free),
+                   [seg(0.25, 0.03)], children=[tip])
+        return Body(tag + "_shoulder", tuple(root_pos), Joint((0, 0, 1), damping=0.3, armature=0.01, gear=6.0, **free),
+                    [seg(0.3, 0.035)], children=[mid])
+
+    base_joints = [Joint(a, kind="slide", damping=0.0, armature=0.0, gear=0.0, **free) for a in ((1, 0, 0), (0, 1, 0), (0, 0, 1))]
+    base_joints += [Joint(a, damping=0.0, armature=0.0, gear=0.0, **free) for a in ((1, 0, 0), (0, 1, 0), (0, 0, 1))]
+    trunk = Body("trunk", (0.0, 0.0, 1.0), None,
+                 [Geom("capsule", 0.09, fromto=(-0.2, 0, 0, 0.2, 0, 0)), Geom("sphere", 0.1, pos=(0.0, 0.0, 0.12))],
+                 children=[limb("limb0", (0.22, 0.0, 0.0), (1, 0, 0)), limb("limb1", (-0.22, 0.0, 0.0), (-1, 0, 0)),
+                           limb("limb2", (0.0, 0.12, 0.0), (0, 1, 0)), limb("limb3", (0.0, -0.12, 0.0), (0, -1, 0))],
+                 joints=base_joints)
+    return ModelSpec("tree_18dof", 0.005, 1, [trunk], gravity=(0.0, 0.0, -9.81))
+
+
 def strip_constraints(spec: ModelSpec) -> ModelSpec:
     """Copy of ``spec`` with joint limits and collisions removed (the 'no contacts' arm)."""
     import copy
@@ -114,8 +152,8 @@ def strip_constraints(spec: ModelSpec) -> ModelSpec:
     s.plane_z = None
 
     def visit(b):
-        if b.joint is not None:
-            b.joint.limited = False
+        for j in b.joint_list():
+            j.limited = False
         for g in b.geoms:
             g.collide = False
         for c in b.children:
@@ -196,6 +234,14 @@ class ModelDesc:
     solref_k: float
     solref_b: float
     solimp: np.ndarray        # (5,)
+    jtype: np.ndarray = None  # (nv,) int32: 0 hinge, 1 slide
+    gravity: np.ndarray = None  # (3,)
+
+    def __post_init__(self):
+        if self.jtype is None:
+            self.jtype = np.zeros(self.nv, np.int32)
+        if self.gravity is None:
+            self.gravity = np.zeros(3)
 
     def link_inertia_matrix(self, i):
         xx, yy, zz, xy, xz, yz = self.inertia[i]
@@ -217,8 +263,12 @@ def mass_matrix(md: ModelDesc, q):
         pi = md.parent[i]
         Rp = np.eye(3) if pi < 0 else R[pi]
         pp = np.zeros(3) if pi < 0 else p[pi]
-        p[i] = pp + Rp @ md.pos[i]
-        R[i] = Rp @ _rot(md.axis[i], q[i])
+        if md.jtype[i] == SLIDE:
+            p[i] = pp + Rp @ (md.pos[i] + q[i] * md.axis[i])
+            R[i] = Rp
+        else:
+            p[i] = pp + Rp @ md.pos[i]
+            R[i] = Rp @ _rot(md.axis[i], q[i])
     # spatial inertia about the world origin: (m, m*c, I_O)
     m = md.mass.copy(); hc = np.zeros((nv, 3)); IO = np.zeros((nv, 3, 3))
     S = np.zeros((nv, 6))
@@ -228,7 +278,10 @@ def mass_matrix(md: ModelDesc, q):
         hc[i] = m[i] * c
         IO[i] = _shift(Ic, m[i], c)
         a = R[i] @ md.axis[i]
-        S[i, :3] = a; S[i, 3:] = np.cross(p[i], a)
+        if md.jtype[i] == SLIDE:
+            S[i, 3:] = a
+        else:
+            S[i, :3] = a; S[i, 3:] = np.cross(p[i], a)
     for i in range(nv - 1, -1, -1):
         pi = md.parent[i]
         if pi >= 0:
@@ -263,7 +316,8 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
 
     def visit(body, parent_link, offset_in_parent):
         pos = np.asarray(body.pos, float)
-        if body.joint is None:
+        joints = body.joint_list()
+        if not joints:
             if parent_link < 0:
                 raise ValueError("static bodies attached to the world are not supported")
             off = offset_in_parent + pos
@@ -271,9 +325,12 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
             for ch in body.children:
                 visit(ch, parent_link, off)
             return
-        link = dict(parent=parent_link, pos=offset_in_parent + pos, joint=body.joint,
-                    parts=[], sites={}, contact=None)
-        links.append(link)
+        # one link per joint; the body's geoms ride on the last one, the others are massless
+        for n, jn in enumerate(joints):
+            link = dict(parent=parent_link, pos=(offset_in_parent + pos) if n == 0 else np.zeros(3), joint=jn,
+                        parts=[], sites={}, contact=None)
+            links.append(link)
+            parent_link = len(links) - 1
         idx = len(links) - 1
         add_geoms(link, body, np.zeros(3))
         for ch in body.children:
@@ -294,7 +351,9 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
         contact_link=-1, contact_pos=np.zeros(3), contact_radius=0.0,
         contact_plane_z=0.0, contact_margin=0.0, contact_invweight=0.0,
         hand_link=-1, hand_pos=np.zeros(3), solref_k=0.0, solref_b=0.0,
-        solimp=np.asarray(spec.solimp, float))
+        solimp=np.asarray(spec.solimp, float),
+        jtype=np.array([SLIDE if l["joint"].kind == "slide" else HINGE for l in links], np.int32),
+        gravity=np.asarray(spec.gravity, float))
     contact_body = None
     for i, l in enumerate(links):
         j = l["joint"]
@@ -305,11 +364,12 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
         md.range_lo[i], md.range_hi[i] = j.range
         md.gear[i] = j.gear
         md.ctrl_lo[i], md.ctrl_hi[i] = j.ctrlrange
-        m = sum(p[0] for p in l["parts"])
-        c = sum(p[0] * p[1] for p in l["parts"]) / m
-        I = sum(_shift(p[2], p[0], c - p[1]) for p in l["parts"])
-        md.mass[i], md.com[i] = m, c
-        md.inertia[i] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+        if l["parts"]:
+            m = sum(p[0] for p in l["parts"])
+            c = sum(p[0] * p[1] for p in l["parts"]) / m
+            I = sum(_shift(p[2], p[0], c - p[1]) for p in l["parts"])
+            md.mass[i], md.com[i] = m, c
+            md.inertia[i] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
         if spec.hand_site in l["sites"]:
             md.hand_link, md.hand_pos = i, l["sites"][spec.hand_site]
         if l["contact"] is not None and spec.plane_z is not None:
@@ -341,7 +401,7 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
                 mm = sum(x[0] for x in parts)
                 body_parts = sum(x[0] * x[1] for x in parts) / mm + off
             for ch in body.children:
-                find(ch, (off + np.asarray(ch.pos, float)) if ch.joint is None else np.zeros(3))
+                find(ch, (off + np.asarray(ch.pos, float)) if not ch.joint_list() else np.zeros(3))
         for b in spec.root:
             find(b, np.zeros(3))
         cw = p[md.contact_link] + R[md.contact_link] @ body_parts
@@ -364,6 +424,8 @@ def get_model(name: str) -> ModelDesc:
             _CACHE[name] = compile_model(reacher_7dof_spec())
         elif name == "reacher_7dof_free":
             _CACHE[name] = compile_model(strip_constraints(reacher_7dof_spec()))
+        elif name == "tree_18dof":
+            _CACHE[name] = compile_model(tree_18dof_spec())
         else:
             raise KeyError(name)
     return _CACHE[name]

@@ -174,14 +174,8 @@ __device__ __forceinline__ bool nonfinite(double x) {
     return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
 }
 
-#ifndef MPPI_F64_BOUNDS
-#define MPPI_F64_BOUNDS 64
-#endif
-template <class T> struct RolloutBounds { static constexpr int value = 64; };
-template <> struct RolloutBounds<double> { static constexpr int value = MPPI_F64_BOUNDS; };
-
 template <class T, class MD>
-__global__ void __launch_bounds__(RolloutBounds<T>::value)
+__global__ void __launch_bounds__(64)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
                const double* __restrict__ ref, int K, int H, int reward_type, double gamma, int explicit_act,
                T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status,
@@ -669,8 +663,7 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
 }
 
 template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArgs& a, hipStream_t s) {
-    static const int lanes = [] { const char* e = getenv("MPPI_LANES_PER_WAVE"); int v = e ? atoi(e) : 64; return (v >= 1 && v <= 64) ? v : 64; }();
-    const dim3 grid((a.K + lanes - 1) / lanes, a.P), block(lanes);
+    const dim3 grid((a.K + 63) / 64, a.P), block(64);      // one wave per block: waves spread over CUs and XCDs
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((rollout_kernel<float, MD>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
                            a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs);

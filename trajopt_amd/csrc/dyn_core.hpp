@@ -84,6 +84,13 @@ MPPI_HD bool wave_any(bool x) {
 #endif
 }
 
+// keeps the instruction scheduler from moving work across this point (device only)
+MPPI_HD void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 constexpr int sym_idx(int i, int j) { return i == j ? i : i + j + 2; }   // xx yy zz xy xz yz
 
 template <class T> struct Vec3 { T v[3]; };
@@ -159,15 +166,14 @@ template <class T, class MD> struct Step {
         else return xp;
     }
 
-    // (q, v, ctrl) -> (q', v') in place.
-    //   want_hand : also evaluate the end-effector site at the input q
-    //   act_mask  : active constraint rows carried from the previous substep (bit i: limit row
-    //               of joint i, bit NV: contact row); start a rollout with all bits set.  The
-    //               active-set iteration converges to the same unique solution from any start;
-    //               starting from the previous substep's set usually needs a single sweep.
-    static MPPI_HD void substep(T (&q)[NV], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
-                                unsigned& act_mask, int& sweeps_out) {
-        T cs[NV], sn[NV];
+    // soft constraint rows of one substep: joint limits (one possible row per joint) and the contact
+    struct Rows {
+        T Dl[NV], arl[NV], sg[NV];   // limit rows: weight (0 = no row), reference acceleration, sign of J
+        T Jc[NV], Dc, arc;           // contact row: Jacobian, weight (0 = no row), reference acceleration
+        bool any;
+    };
+
+    static MPPI_HD void trig(const T (&q)[NV], T (&cs)[NV], T (&sn)[NV]) {
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             if constexpr (MD::jtype[i] == 1) {
@@ -179,22 +185,23 @@ template <class T, class MD> struct Step {
                 sn[i] = (MD::axis_sign[i] > 0) ? s : -s;
             }
         });
+    }
 
-        // ---- points of interest in world coordinates ----------------------------------------
+    // end-effector site in world coordinates
+    static MPPI_HD Vec3<T> hand_site(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV]) {
         if constexpr (MD::hand_link >= 0) {
-            if (want_hand) {
-                Vec3<T> tmp[NV];
-                out.hand = point_to_world<MD::hand_link>(q, cs, sn, {{T(MD::hand_pos[0]), T(MD::hand_pos[1]), T(MD::hand_pos[2])}}, tmp);
-            }
+            Vec3<T> tmp[NV];
+            return point_to_world<MD::hand_link>(q, cs, sn, {{T(MD::hand_pos[0]), T(MD::hand_pos[1]), T(MD::hand_pos[2])}}, tmp);
+        } else {
+            return {{T(0), T(0), T(0)}};
         }
+    }
 
+    // actuation (clamped to the control range), joint damping and bias forces
+    static MPPI_HD void smooth_force(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV],
+                                     const T (&ctrl)[NV], T (&fs)[NV]) {
         T bias[NV];
         bias_forces(q, cs, sn, qd, bias);
-        T M[NV][NV];     // lower triangle used: M[i][j], i >= j
-        mass_matrix(q, cs, sn, M);
-
-        // ---- smooth force -------------------------------------------------------------------
-        T fs[NV];
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             T u = ctrl[i];
@@ -202,33 +209,30 @@ template <class T, class MD> struct Step {
             u = u > T(MD::ctrl_hi[i]) ? T(MD::ctrl_hi[i]) : u;
             fs[i] = T(MD::gear[i]) * u - T(MD::damping[i]) * qd[i] - bias[i];
         });
+    }
 
-        // ---- soft constraint rows ------------------------------------------------------------
-        T fc[NV];
-        static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
-        int sweeps = 0;
-        bool any_row = false;
-        T Dl[NV], arl[NV], sg[NV];          // limit rows: weight (0 = no row), reference accel, sign of J
+    static MPPI_HD void build_rows(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], Rows& r) {
+        r.any = false;
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
-            Dl[i] = T(0); arl[i] = T(0); sg[i] = T(1);
+            r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1);
             if constexpr (MD::limited[i] != 0) {
                 // at most one side can be violated; evaluated without branches
                 const T lo = q[i] - T(MD::range_lo[i]);
                 const T hi = T(MD::range_hi[i]) - q[i];
                 const bool blo = lo < hi;
                 const T pos = blo ? lo : hi;
-                sg[i] = blo ? T(1) : T(-1);
+                r.sg[i] = blo ? T(1) : T(-1);
                 T D, ar;
-                row_constants(pos, sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
+                row_constants(pos, r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
                 const bool on = pos < T(0);
-                Dl[i] = on ? D : T(0);
-                arl[i] = on ? ar : T(0);
-                any_row |= on;
+                r.Dl[i] = on ? D : T(0);
+                r.arl[i] = on ? ar : T(0);
+                r.any |= on;
             }
         });
-        T Jc[NV], Dc = T(0), arc = T(0);
-        static_for<NV>([&](auto Ic) { Jc[Ic] = T(0); });
+        r.Dc = T(0); r.arc = T(0);
+        static_for<NV>([&](auto Ic) { r.Jc[Ic] = T(0); });
         if constexpr (MD::contact_link >= 0) {
             constexpr int L = MD::contact_link;
             Vec3<T> xc[NV];
@@ -249,88 +253,136 @@ template <class T, class MD> struct Step {
                         else zp = zl[p];
                         zl[i] = to_child<A>(cs[i], sn[i], zp);
                         // (e_A x x)[U] = -x[W], (e_A x x)[W] = x[U]
-                        Jc[i] = T(MD::axis_sign[i]) * (zl[i].v[W] * xc[i].v[U] - zl[i].v[U] * xc[i].v[W]);
-                        vel += Jc[i] * qd[i];
+                        r.Jc[i] = T(MD::axis_sign[i]) * (zl[i].v[W] * xc[i].v[U] - zl[i].v[U] * xc[i].v[W]);
+                        vel += r.Jc[i] * qd[i];
                     }
                 });
-                row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), Dc, arc);
-                any_row = true;
+                row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), r.Dc, r.arc);
+                r.any = true;
             }
         }
+    }
 
-        if (any_row) {
-            bool actl[NV], actc = (Dc > T(0)) && ((act_mask >> NV) & 1u);
-            static_for<NV>([&](auto Ic) { actl[Ic] = (Dl[Ic] > T(0)) && ((act_mask >> Ic) & 1u); });
+    // semi-implicit Euler with implicit joint damping: (M + h B) a = fs + fc, v += h a, q += h v.
+    // The factor of M + h B does not depend on the forces and may be computed ahead of them.
+    struct DampedFactor { T L[NV][NV], inv[NV]; };       // inv[j] = 1 / L_jj
+    static MPPI_HD void factor_damped(const T (&M)[NV][NV], DampedFactor& f) {
+        T hb[NV];
+        static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::H * MD::damping[Ic]); });
+        chol_factor<false>(M, hb, T(0), hb, f.L, f.inv);
+    }
+
+    // exact active-set solve of the soft constraint rows: fc = J^T f with f >= 0 on the active rows.
+    //   act_mask : active rows carried from the previous substep (bit i: limit row of joint i, bit NV:
+    //              contact row); start a rollout with all bits set.  The iteration converges to the same
+    //              unique solution from any start; starting from the previous set usually needs one sweep.
+    //   damped   : receives the factor of M + h B, which integrate() needs afterwards; it is computed
+    //              inside the first sweep, column by column next to the constraint system's own factor
+    //              (two independent chains keep a lone wave's pipeline busy).
+    // The loop is uniform over the wave: lanes whose set has settled repeat the same solve (same result)
+    // until every lane has settled, so the only cross-lane operation is one vote per sweep.
+    static MPPI_HD void constraint_forces(const T (&M)[NV][NV], const T (&fs)[NV], const Rows& r, unsigned& act_mask,
+                                          T (&fc)[NV], int& sweeps_out, DampedFactor& damped) {
+        static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
+        int sweeps = 0;
+        if (wave_any(r.any)) {
+            // active weight of every row: its D while active, 0 while inactive or absent
+            T dg[NV], dc = ((act_mask >> NV) & 1u) ? r.Dc : T(0);
+            static_for<NV>([&](auto Ic) { dg[Ic] = ((act_mask >> Ic) & 1u) ? r.Dl[Ic] : T(0); });
             T acc[NV], resl[NV], resc = T(0);
-            const bool wave_contact = wave_any(Dc > T(0));
-            for (;;) {
-                sweeps++;
-                T dg[NV];
-                static_for<NV>([&](auto Ic) {
-                    constexpr int i = Ic;
-                    dg[i] = actl[i] ? Dl[i] : T(0);
-                    acc[i] = fs[i] + sg[i] * dg[i] * arl[i];
-                });
-                if (wave_contact) {
-                    const T dc = actc ? Dc : T(0);
-                    static_for<NV>([&](auto Ic) { acc[Ic] += dc * arc * Jc[Ic]; });
-                    chol_solve<true>(M, dg, dc, Jc, acc);
-                } else {
-                    chol_solve<false>(M, dg, T(0), Jc, acc);
-                }
+            const bool wave_contact = wave_any(r.Dc > T(0));
+            auto right_hand_side = [&]() {
+                static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + r.sg[Ic] * dg[Ic] * r.arl[Ic]; });
+                if (wave_contact) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
+            };
+            // residual signs decide the next active set; true if this lane's set changed
+            auto settle = [&]() -> bool {
                 bool changed = false;
                 static_for<NV>([&](auto Ic) {
                     constexpr int i = Ic;
                     if constexpr (MD::limited[i] != 0) {
-                        resl[i] = sg[i] * acc[i] - arl[i];
-                        const bool a = (Dl[i] > T(0)) && (resl[i] < T(0));
-                        changed |= (a != actl[i]);
-                        actl[i] = a;
+                        resl[i] = r.sg[i] * acc[i] - r.arl[i];
+                        const T nd = (resl[i] < T(0)) ? r.Dl[i] : T(0);
+                        changed |= (nd != dg[i]);
+                        dg[i] = nd;
                     }
                 });
                 if constexpr (MD::contact_link >= 0) {
                     T ja = T(0);
-                    static_for<NV>([&](auto Ic) { ja += Jc[Ic] * acc[Ic]; });
-                    resc = ja - arc;
-                    const bool a = (Dc > T(0)) && (resc < T(0));
-                    changed |= (a != actc);
-                    actc = a;
+                    static_for<NV>([&](auto Ic) { ja += r.Jc[Ic] * acc[Ic]; });
+                    resc = ja - r.arc;
+                    const T nd = (resc < T(0)) ? r.Dc : T(0);
+                    changed |= (nd != dc);
+                    dc = nd;
                 }
-                if (!changed || sweeps >= 12) break;
+                return changed;
+            };
+            sweeps = 1;
+            right_hand_side();
+            T hb[NV];
+            static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::H * MD::damping[Ic]); });
+            if (wave_contact) chol_solve_and_factor<true>(M, dg, dc, r.Jc, acc, hb, damped.L, damped.inv);
+            else chol_solve_and_factor<false>(M, dg, T(0), r.Jc, acc, hb, damped.L, damped.inv);
+            bool changed = settle();
+            while (wave_any(changed) && sweeps < 12) {
+                sweeps++;
+                right_hand_side();
+                if (wave_contact) chol_solve<true>(M, dg, dc, r.Jc, acc);
+                else chol_solve<false>(M, dg, T(0), r.Jc, acc);
+                changed = settle();
             }
             static_for<NV>([&](auto Ic) {
                 constexpr int i = Ic;
-                if constexpr (MD::limited[i] != 0) fc[i] = actl[i] ? -sg[i] * Dl[i] * resl[i] : T(0);
+                if constexpr (MD::limited[i] != 0) fc[i] = -r.sg[i] * dg[i] * resl[i];
             });
             if constexpr (MD::contact_link >= 0) {
-                if (actc) {
-                    const T f = -Dc * resc;
-                    static_for<NV>([&](auto Ic) { fc[Ic] += Jc[Ic] * f; });
-                }
+                const T f = -dc * resc;
+                static_for<NV>([&](auto Ic) { fc[Ic] += r.Jc[Ic] * f; });
             }
             // rows that do not exist start active when they next appear
             unsigned m = 0u;
-            static_for<NV>([&](auto Ic) { m |= ((Dl[Ic] > T(0)) && !actl[Ic]) ? 0u : (1u << Ic); });
-            m |= ((Dc > T(0)) && !actc) ? 0u : (1u << NV);
+            static_for<NV>([&](auto Ic) { m |= ((r.Dl[Ic] > T(0)) && !(dg[Ic] > T(0))) ? 0u : (1u << Ic); });
+            m |= ((r.Dc > T(0)) && !(dc > T(0))) ? 0u : (1u << NV);
             act_mask = m;
         } else {
             act_mask = ~0u;
+            factor_damped(M, damped);
         }
         sweeps_out = sweeps;
+    }
 
-        // ---- semi-implicit Euler with implicit joint damping ----------------------------------
-        T qacc[NV], hb[NV];
-        static_for<NV>([&](auto Ic) {
-            constexpr int i = Ic;
-            hb[i] = T(MD::H * MD::damping[i]);
-            qacc[i] = fs[i] + fc[i];
-        });
-        chol_solve<false>(M, hb, T(0), hb, qacc);
+    // v += h a with (M + h B) a = fs + fc, then q += h v
+    static MPPI_HD void integrate(const DampedFactor& f, const T (&fs)[NV], const T (&fc)[NV], T (&q)[NV], T (&qd)[NV]) {
+        T qacc[NV];
+        static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
+        chol_apply(f.L, f.inv, qacc);
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             qd[i] = qd[i] + T(MD::H) * qacc[i];
             q[i] = q[i] + T(MD::H) * qd[i];
         });
+    }
+
+    // (q, v, ctrl) -> (q', v') in place.
+    //   want_hand : also evaluate the end-effector site at the input q
+    //   act_mask  : see constraint_forces
+    static MPPI_HD void substep(T (&q)[NV], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
+                                unsigned& act_mask, int& sweeps_out) {
+        T cs[NV], sn[NV];
+        trig(q, cs, sn);
+        if constexpr (MD::hand_link >= 0) {
+            if (want_hand) out.hand = hand_site(q, cs, sn);
+        }
+        T fs[NV];
+        smooth_force(q, cs, sn, qd, ctrl, fs);
+        T M[NV][NV];     // lower triangle used: M[i][j], i >= j
+        mass_matrix(q, cs, sn, M);
+        Rows rows;
+        build_rows(q, cs, sn, qd, rows);
+        DampedFactor f;
+        T fc[NV];
+        constraint_forces(M, fs, rows, act_mask, fc, sweeps_out, f);
+        integrate(f, fs, fc, q, qd);
     }
 
     // bias forces: recursive Newton-Euler with zero joint acceleration, link-local coordinates
@@ -491,37 +543,89 @@ template <class T, class MD> struct Step {
         D = imp * rcp_t((T(1) - imp) * invweight);
     }
 
-    // solve (M + diag(dg) + dc * Jc Jc^T) x = b by Cholesky; M (lower triangle) is read, not modified;
-    // b is overwritten with x
+    // ---- dense solver -----------------------------------------------------------------------------
+    // Cholesky, written right-looking: a finished column is applied to the rest of the matrix at once,
+    // and the forward substitution rides along as one more row.  Every sum runs in the order of the
+    // textbook left-looking form.  inv[j] = 1 / L_jj.
+
+    // A = M + diag(dg) + dc * Jc Jc^T, lower triangle
+    template <bool CONTACT>
+    static MPPI_HD void build_system(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&A)[NV][NV]) {
+        static_for<NV>([&](auto In) {
+            constexpr int i = In;
+            static_for<i + 1>([&](auto Jn) {
+                constexpr int j = Jn;
+                T a = M[i][j];
+                if constexpr (i == j) a += dg[i];
+                if constexpr (CONTACT) a += dc * Jc[i] * Jc[j];
+                A[i][j] = a;
+            });
+        });
+    }
+    // column j of the factor (in place), applied to the columns right of it
+    template <int j>
+    static MPPI_HD void eliminate_column(T (&A)[NV][NV], T (&inv)[NV]) {
+        inv[j] = rsqrt_t(A[j][j]);
+        static_for<NV - 1 - j>([&](auto In) { A[j + 1 + In][j] *= inv[j]; });
+        static_for<NV - 1 - j>([&](auto Kn) {
+            constexpr int k = j + 1 + Kn;
+            static_for<NV - k>([&](auto In) { constexpr int i = k + In; A[i][k] -= A[i][j] * A[k][j]; });
+        });
+    }
+    // forward substitution step j (b_j becomes y_j, later entries accumulate)
+    template <int j>
+    static MPPI_HD void forward_column(const T (&L)[NV][NV], const T (&inv)[NV], T (&b)[NV]) {
+        b[j] *= inv[j];
+        static_for<NV - 1 - j>([&](auto In) { constexpr int i = j + 1 + In; b[i] -= L[i][j] * b[j]; });
+    }
+    static MPPI_HD void back_substitute(const T (&L)[NV][NV], const T (&inv)[NV], T (&b)[NV]) {
+        static_for<NV>([&](auto Kn) {
+            constexpr int k = NV - 1 - Kn;
+            b[k] *= inv[k];
+            static_for<k>([&](auto In) { constexpr int i = k - 1 - In; b[i] -= L[k][i] * b[k]; });
+        });
+    }
+
+    // Cholesky factor of M + diag(dg) + dc * Jc Jc^T; M (lower triangle) is read, not modified.
+    // The strict lower triangle of L and inv are written.
+    template <bool CONTACT>
+    static MPPI_HD void chol_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&L)[NV][NV],
+                                    T (&inv)[NV]) {
+        build_system<CONTACT>(M, dg, dc, Jc, L);
+        static_for<NV>([&](auto Jn) { eliminate_column<Jn>(L, inv); });
+    }
+    // b <- (L L^T)^-1 b
+    static MPPI_HD void chol_apply(const T (&L)[NV][NV], const T (&inv)[NV], T (&b)[NV]) {
+        static_for<NV>([&](auto Jn) { forward_column<Jn>(L, inv, b); });
+        back_substitute(L, inv, b);
+    }
+    // solve (M + diag(dg) + dc * Jc Jc^T) x = b; b is overwritten with x
     template <bool CONTACT>
     static MPPI_HD void chol_solve(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&b)[NV]) {
         T L[NV][NV], inv[NV];
+        build_system<CONTACT>(M, dg, dc, Jc, L);
         static_for<NV>([&](auto Jn) {
-            constexpr int j = Jn;
-            T s = M[j][j] + dg[j];
-            if constexpr (CONTACT) s += dc * Jc[j] * Jc[j];
-            static_for<j>([&](auto Kn) { s -= L[j][Kn] * L[j][Kn]; });
-            inv[j] = rsqrt_t(s);
-            static_for<NV - 1 - j>([&](auto In) {
-                constexpr int i = j + 1 + In;
-                T t = M[i][j];
-                if constexpr (CONTACT) t += dc * Jc[i] * Jc[j];
-                static_for<j>([&](auto Kn) { t -= L[i][Kn] * L[j][Kn]; });
-                L[i][j] = t * inv[j];
-            });
+            eliminate_column<Jn>(L, inv);
+            forward_column<Jn>(L, inv, b);
         });
-        static_for<NV>([&](auto In) {
-            constexpr int i = In;
-            T t = b[i];
-            static_for<i>([&](auto Kn) { t -= L[i][Kn] * b[Kn]; });
-            b[i] = t * inv[i];
+        back_substitute(L, inv, b);
+    }
+    // chol_solve for system 1 = M + diag(dg) + dc * Jc Jc^T with right-hand side b and, column by column
+    // next to it, the factor (L2, inv2) of system 2 = M + diag(d2): two independent chains of dependent
+    // instructions, which a lone wave issues faster than one after the other
+    template <bool CONTACT>
+    static MPPI_HD void chol_solve_and_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&b)[NV],
+                                              const T (&d2)[NV], T (&L2)[NV][NV], T (&inv2)[NV]) {
+        T L[NV][NV], inv[NV];
+        build_system<CONTACT>(M, dg, dc, Jc, L);
+        build_system<false>(M, d2, T(0), Jc, L2);
+        static_for<NV>([&](auto Jn) {
+            eliminate_column<Jn>(L, inv);
+            eliminate_column<Jn>(L2, inv2);
+            forward_column<Jn>(L, inv, b);
+            sched_fence();
         });
-        static_for<NV>([&](auto In) {
-            constexpr int i = NV - 1 - In;
-            T t = b[i];
-            static_for<NV - 1 - i>([&](auto Kn) { constexpr int k = i + 1 + Kn; t -= L[k][i] * b[k]; });
-            b[i] = t * inv[i];
-        });
+        back_substitute(L, inv, b);
     }
 };
 

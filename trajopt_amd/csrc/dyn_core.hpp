@@ -95,26 +95,38 @@ constexpr int sym_idx(int i, int j) { return i == j ? i : i + j + 2; }   // xx y
 
 template <class T> struct Vec3 { T v[3]; };
 
-template <class T> MPPI_HD Vec3<T> cross(const Vec3<T>& a, const Vec3<T>& b) {
+// Two values that go through the same arithmetic side by side (angular and linear velocity, force and
+// moment, ...).  On gfx950 arithmetic on such a pair is one packed instruction (v_pk_fma_f32 and friends)
+// with scalars broadcast for free, which halves the issue slots of everything written in pairs; fp64
+// pairs are simply two instructions.  [0] and [1] address the halves.
+template <class T> struct PairOf;
+template <> struct PairOf<float> { typedef float type __attribute__((vector_size(8))); };
+template <> struct PairOf<double> { typedef double type __attribute__((vector_size(16))); };
+template <class T> using Pair = typename PairOf<T>::type;
+template <class T> MPPI_HD Pair<T> make_pair_of(T a, T b) { Pair<T> p = {a, b}; return p; }
+template <class T> MPPI_HD Vec3<T> half(const Vec3<Pair<T>>& a, int h) { return {{a.v[0][h], a.v[1][h], a.v[2][h]}}; }
+
+// a x b for any mix of scalar and paired operands
+template <class EA, class EB> MPPI_HD auto cross(const Vec3<EA>& a, const Vec3<EB>& b) -> Vec3<decltype(a.v[0] * b.v[0])> {
     return {{a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0]}};
 }
-template <class T> MPPI_HD Vec3<T> add(const Vec3<T>& a, const Vec3<T>& b) {
+template <class E> MPPI_HD Vec3<E> add(const Vec3<E>& a, const Vec3<E>& b) {
     return {{a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2]}};
 }
-template <class T> MPPI_HD Vec3<T> scale(T s, const Vec3<T>& a) { return {{s * a.v[0], s * a.v[1], s * a.v[2]}}; }
+template <class T, class E> MPPI_HD Vec3<E> scale(T s, const Vec3<E>& a) { return {{s * a.v[0], s * a.v[1], s * a.v[2]}}; }
 
 // rotation about coordinate axis A by angle (c, s): parent coordinates from child coordinates
-template <int A, class T> MPPI_HD Vec3<T> to_parent(T c, T s, const Vec3<T>& x) {
+template <int A, class T, class E> MPPI_HD Vec3<E> to_parent(T c, T s, const Vec3<E>& x) {
     constexpr int U = (A + 1) % 3, W = (A + 2) % 3;
-    Vec3<T> y;
+    Vec3<E> y;
     y.v[A] = x.v[A];
     y.v[U] = c * x.v[U] - s * x.v[W];
     y.v[W] = s * x.v[U] + c * x.v[W];
     return y;
 }
-template <int A, class T> MPPI_HD Vec3<T> to_child(T c, T s, const Vec3<T>& x) {
+template <int A, class T, class E> MPPI_HD Vec3<E> to_child(T c, T s, const Vec3<E>& x) {
     constexpr int U = (A + 1) % 3, W = (A + 2) % 3;
-    Vec3<T> y;
+    Vec3<E> y;
     y.v[A] = x.v[A];
     y.v[U] = c * x.v[U] + s * x.v[W];
     y.v[W] = c * x.v[W] - s * x.v[U];
@@ -124,7 +136,7 @@ template <int A, class T> MPPI_HD Vec3<T> to_child(T c, T s, const Vec3<T>& x) {
 // spatial inertia about a frame origin: mass, first moment h = m*c, rotational inertia I (sym 6)
 template <class T> struct SpInertia { T m; Vec3<T> h; T I[6]; };
 
-template <class T> MPPI_HD Vec3<T> sym_mul(const T (&I)[6], const Vec3<T>& w) {
+template <class T, class E> MPPI_HD Vec3<E> sym_mul(const T (&I)[6], const Vec3<E>& w) {
     return {{I[0] * w.v[0] + I[3] * w.v[1] + I[4] * w.v[2],
              I[3] * w.v[0] + I[1] * w.v[1] + I[5] * w.v[2],
              I[4] * w.v[0] + I[5] * w.v[1] + I[2] * w.v[2]}};
@@ -385,63 +397,71 @@ template <class T, class MD> struct Step {
         integrate(f, fs, fc, q, qd);
     }
 
-    // bias forces: recursive Newton-Euler with zero joint acceleration, link-local coordinates
+    // bias forces: recursive Newton-Euler with zero joint acceleration, link-local coordinates.
+    // Velocity and velocity-product acceleration travel as pairs, angular {omega, alpha} and linear {v, a}
+    // (same transforms, same inertia products); force and moment travel back as a pair too.
     static MPPI_HD void bias_forces(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], T (&bias)[NV]) {
-        Vec3<T> om[NV], vl[NV], al[NV], ac[NV];       // angular/linear velocity, angular/linear spatial accel
-        Vec3<T> fn[NV], ff[NV];                       // moment about link origin, force
+        using P = Pair<T>;
+        Vec3<P> ang[NV], lin[NV];       // [0]: velocity, [1]: acceleration
+        Vec3<P> fm[NV];                 // [0]: force, [1]: moment about the link origin
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             constexpr int p = MD::parent[i];
             constexpr int A = MD::axis_id[i];
             const Vec3<T> r = off_<i>(q);
-            Vec3<T> w, v, a_w, a_v;
+            Vec3<P> a, l;
             if constexpr (p < 0) {
-                w = {{T(0), T(0), T(0)}}; v = w; a_w = w; a_v = w;
+                const P z = make_pair_of(T(0), T(0));
+                a = {{z, z, z}};
+                l = a;
                 // gravity enters as an upward acceleration of the world
-                if constexpr (MD::has_gravity)
-                    a_v = to_child<A>(cs[i], sn[i], Vec3<T>{{T(-MD::gravity[0]), T(-MD::gravity[1]), T(-MD::gravity[2])}});
+                if constexpr (MD::has_gravity) {
+                    const Vec3<T> g = to_child<A>(cs[i], sn[i], Vec3<T>{{T(-MD::gravity[0]), T(-MD::gravity[1]), T(-MD::gravity[2])}});
+                    static_for<3>([&](auto Cn) { l.v[Cn][1] = g.v[Cn]; });
+                }
             } else {
-                w = to_child<A>(cs[i], sn[i], om[p]);
-                v = to_child<A>(cs[i], sn[i], add(vl[p], cross(om[p], r)));
-                a_w = to_child<A>(cs[i], sn[i], al[p]);
-                a_v = to_child<A>(cs[i], sn[i], add(ac[p], cross(al[p], r)));
+                a = to_child<A>(cs[i], sn[i], ang[p]);
+                l = to_child<A>(cs[i], sn[i], add(lin[p], cross(ang[p], r)));
             }
             // joint rate along / about axis A; velocity-product acceleration V x (S qd)
             Vec3<T> sq = {{T(0), T(0), T(0)}};
             sq.v[A] = T(MD::axis_sign[i]) * qd[i];
             if constexpr (MD::jtype[i] == 1) {
-                a_v = add(a_v, cross(w, sq));
-                v.v[A] += sq.v[A];
+                const Vec3<T> da = cross(half<T>(a, 0), sq);
+                static_for<3>([&](auto Cn) { l.v[Cn][1] += da.v[Cn]; });
+                l.v[A][0] += sq.v[A];
             } else {
-                a_w = add(a_w, cross(w, sq));
-                a_v = add(a_v, cross(v, sq));
-                w.v[A] += sq.v[A];
+                const Vec3<T> dw = cross(half<T>(a, 0), sq), dv = cross(half<T>(l, 0), sq);
+                static_for<3>([&](auto Cn) { a.v[Cn][1] += dw.v[Cn]; l.v[Cn][1] += dv.v[Cn]; });
+                a.v[A][0] += sq.v[A];
             }
-            om[i] = w; vl[i] = v; al[i] = a_w; ac[i] = a_v;
+            ang[i] = a; lin[i] = l;
             const T m = T(MD::mass[i]);
             const Vec3<T> h = mc_<i>();
             const T IO[6] = {T(MD::IO[i][0]), T(MD::IO[i][1]), T(MD::IO[i][2]), T(MD::IO[i][3]), T(MD::IO[i][4]), T(MD::IO[i][5])};
-            const Vec3<T> lV = add(scale(m, v), cross(w, h));
-            const Vec3<T> nV = add(sym_mul(IO, w), cross(h, v));
-            const Vec3<T> lA = add(scale(m, a_v), cross(a_w, h));
-            const Vec3<T> nA = add(sym_mul(IO, a_w), cross(h, a_v));
-            fn[i] = add(nA, add(cross(w, nV), cross(v, lV)));
-            ff[i] = add(lA, cross(w, lV));
+            // momentum {of the velocity, of the acceleration}: linear and angular about the link origin
+            const Vec3<P> lm = add(scale(m, l), cross(a, h));
+            const Vec3<P> am = add(sym_mul(IO, a), cross(h, l));
+            const Vec3<T> w = half<T>(a, 0), v = half<T>(l, 0), lV = half<T>(lm, 0), nV = half<T>(am, 0);
+            const Vec3<T> f = add(half<T>(lm, 1), cross(w, lV));
+            const Vec3<T> n = add(half<T>(am, 1), add(cross(w, nV), cross(v, lV)));
+            static_for<3>([&](auto Cn) { fm[i].v[Cn] = make_pair_of(f.v[Cn], n.v[Cn]); });
         });
         static_for<NV>([&](auto Ic) {
             constexpr int i = NV - 1 - Ic;
             constexpr int p = MD::parent[i];
             constexpr int A = MD::axis_id[i];
-            bias[i] = T(MD::axis_sign[i]) * (MD::jtype[i] == 1 ? ff[i].v[A] : fn[i].v[A]);
+            bias[i] = T(MD::axis_sign[i]) * fm[i].v[A][MD::jtype[i] == 1 ? 0 : 1];
             if constexpr (p >= 0) {
                 const Vec3<T> r = off_<i>(q);
-                const Vec3<T> f = to_parent<A>(cs[i], sn[i], ff[i]);
-                const Vec3<T> n = to_parent<A>(cs[i], sn[i], fn[i]);
-                ff[p] = add(ff[p], f);
-                fn[p] = add(fn[p], add(n, cross(r, f)));
+                const Vec3<P> up = to_parent<A>(cs[i], sn[i], fm[i]);
+                const Vec3<T> rf = cross(r, half<T>(up, 0));
+                static_for<3>([&](auto Cn) {
+                    fm[p].v[Cn] += up.v[Cn];
+                    fm[p].v[Cn][1] += rf.v[Cn];
+                });
             }
         });
-
     }
 
     // joint-space inertia (lower triangle, armature included): composite rigid bodies in link coordinates
@@ -468,16 +488,20 @@ template <class T, class MD> struct Step {
                 Vec3<T> ea = {{T(0), T(0), T(0)}};
                 constexpr T sgn = T(MD::axis_sign[i]);
                 ea.v[A] = sgn;
+                Vec3<T> n, f;
                 if constexpr (MD::jtype[i] == 1) {
-                    const Vec3<T> n = cross(Ic_[i].h, ea);
-                    const Vec3<T> f = scale(Ic_[i].m, ea);
+                    n = cross(Ic_[i].h, ea);
+                    f = scale(Ic_[i].m, ea);
                     M[i][i] = Ic_[i].m + T(MD::armature[i]);
-                    walk_up<i, i>(q, cs, sn, n, f, M);
                 } else {
-                    Vec3<T> n = {{sgn * Ic_[i].I[sym_idx(0, A)], sgn * Ic_[i].I[sym_idx(1, A)], sgn * Ic_[i].I[sym_idx(2, A)]}};
-                    Vec3<T> f = cross(ea, Ic_[i].h);
+                    n = {{sgn * Ic_[i].I[sym_idx(0, A)], sgn * Ic_[i].I[sym_idx(1, A)], sgn * Ic_[i].I[sym_idx(2, A)]}};
+                    f = cross(ea, Ic_[i].h);
                     M[i][i] = Ic_[i].I[sym_idx(A, A)] + T(MD::armature[i]);
-                    walk_up<i, i>(q, cs, sn, n, f, M);
+                }
+                if constexpr (p >= 0) {
+                    Vec3<Pair<T>> fm;
+                    static_for<3>([&](auto Cn) { fm.v[Cn] = make_pair_of(f.v[Cn], n.v[Cn]); });
+                    walk_up<i, i>(q, cs, sn, fm, M);
                 }
             }
             if constexpr (p >= 0) {
@@ -514,18 +538,18 @@ template <class T, class MD> struct Step {
 
     }
 
-    // carry the force (n about origin of link I, f) of column COL up the tree, filling M[COL][ancestor]
+    // carry the pair {force, moment about the origin of link I} of column COL up the tree, filling M[COL][ancestor]
     template <int COL, int I>
-    static MPPI_HD void walk_up(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& n, const Vec3<T>& f,
-                                T (&M)[NV][NV]) {
+    static MPPI_HD void walk_up(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const Vec3<Pair<T>>& fm, T (&M)[NV][NV]) {
         constexpr int p = MD::parent[I];
         if constexpr (p >= 0) {
             constexpr int A = MD::axis_id[I];
             const Vec3<T> r = off_<I>(q);
-            const Vec3<T> fp = to_parent<A>(cs[I], sn[I], f);
-            const Vec3<T> np = add(to_parent<A>(cs[I], sn[I], n), cross(r, fp));
-            M[COL][p] = T(MD::axis_sign[p]) * (MD::jtype[p] == 1 ? fp.v[MD::axis_id[p]] : np.v[MD::axis_id[p]]);
-            walk_up<COL, p>(q, cs, sn, np, fp, M);
+            Vec3<Pair<T>> up = to_parent<A>(cs[I], sn[I], fm);
+            const Vec3<T> rf = cross(r, half<T>(up, 0));
+            static_for<3>([&](auto Cn) { up.v[Cn][1] += rf.v[Cn]; });
+            M[COL][p] = T(MD::axis_sign[p]) * up.v[MD::axis_id[p]][MD::jtype[p] == 1 ? 0 : 1];
+            walk_up<COL, p>(q, cs, sn, up, M);
         }
     }
 

@@ -80,15 +80,14 @@ extern "C" void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], ui
     for (int i = 0; i < 4; i++) out[i] = c[i];
 }
 
-// two uniforms -> two N(0,1) (Box-Muller)
+// two uniforms -> two N(0,1) (Box-Muller) on the hardware transcendental units: log2, square root, and
+// sine / cosine of an angle given in revolutions (about 1e-6 absolute, far below what a sampler needs)
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
     const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
     const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);          // [0, 1)
-    const float r = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.28318530717958647692f * u2, &s, &c);
-    n0 = r * c;
-    n1 = r * s;
+    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -247,7 +246,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
 
 // one fp64 env.step of the real environment; io: in [q(nv) v(nv) target(3) act(nv) alpha refrow(3)], out [q v obs(2nv+6) reward]
 template <class MD>
-__global__ void env_step_kernel(const double* __restrict__ in, int reward_type, int has_ref, int forward_only,
+__global__ void __launch_bounds__(64) env_step_kernel(const double* __restrict__ in, int reward_type, int has_ref, int forward_only,
                                 double* __restrict__ out) {
     constexpr int NV = MD::NV;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

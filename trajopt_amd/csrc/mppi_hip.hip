@@ -5,6 +5,7 @@
 //   rollout_kernel<T, MD>                       H env steps x FRAME_SKIP substeps, fused reward + discounted return
 //   weights_kernel<T>                           max / arg-max over K, S_k = exp(kappa (R_k - Rmax)), sum S
 //   wsum_kernel<T>                              sum_k S_k eps[t][j][k] for every (t, j)
+//   update_rows_kernel<T, NV>                   single-rank update in one launch (weights + sums + act_sequence)
 //   merge_kernel                                rank-ordered merge of shard statistics, writes act_sequence
 //   shift_kernel                                receding-horizon shift + tail fill
 //   env_step_kernel<MD>                         one fp64 env.step for the real environment
@@ -465,55 +466,65 @@ __global__ void __launch_bounds__(256) wsum_kernel(const double* __restrict__ S,
     if (tid == 0) part[3 + hm] = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
 }
 
-// Single-rank update in one launch: block (hm, planner) finds Rmax / first arg-max and sum S itself (every
-// block gets the same values, in the same fixed order), forms its weighted sum and writes act_sequence[hm].
-// Same arithmetic, in the same order, as weights_kernel + wsum_kernel + merge_kernel with one rank.
-template <class T>
-__global__ void __launch_bounds__(256) update_fused_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
-                                                          int k_offset, double* __restrict__ base, double* __restrict__ part,
-                                                          double* __restrict__ result) {
-    __shared__ double s_v[4];
-    __shared__ int s_i[4];
-    const int hm = blockIdx.x, HM = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + hm) * K;
-    base += (size_t)blockIdx.y * HM; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
-    // max / first arg-max: same 1024-strided partition as weights_kernel so ties resolve identically
+// Single-rank update in one launch, one block per (step t, planner): the block finds Rmax / first arg-max
+// itself (every block gets the same values, in the same fixed order), evaluates every weight
+// S_k = exp(kappa (R_k - Rmax)) once and accumulates sum S and the NV weighted sums of its step, then
+// writes act_sequence[t][:].  Any block size that is a multiple of 64 up to 1024.
+template <class T, int NV>
+__global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
+                                                           int k_offset, double* __restrict__ base, double* __restrict__ part,
+                                                           double* __restrict__ result) {
+    __shared__ double s_v[16][NV + 1];
+    __shared__ int s_i[16];
+    const int t = blockIdx.x, H = gridDim.x, HM = H * NV, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + (size_t)t * NV) * K;
+    base += (size_t)blockIdx.y * HM + t * NV; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
     double bv = -DBL_MAX;
     int bi = INT_MAX;
-    for (int k = tid; k < K; k += 256) argmax_combine(bv, bi, (double)R[k], k);
+    for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const double ov = shfl_xor_d(bv, m);
         const int oi = __shfl_xor(bi, m, 64);
         argmax_combine(bv, bi, ov, oi);
     }
-    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    if (lane == 0) { s_v[wave][0] = bv; s_i[wave] = bi; }
     __syncthreads();
-    bv = s_v[0]; bi = s_i[0];
-    for (int w = 1; w < 4; w++) argmax_combine(bv, bi, s_v[w], s_i[w]);
+    bv = s_v[0][0]; bi = s_i[0];
+    for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
     __syncthreads();
-    double num = 0.0, den = 0.0;
-    for (int k = tid; k < K; k += 256) {
+    double acc[NV + 1];            // [NV]: sum of the weights
+#pragma unroll
+    for (int j = 0; j <= NV; j++) acc[j] = 0.0;
+    for (int k = tid; k < K; k += nthreads) {
         const double sk = exp(kappa * ((double)R[k] - bv));
-        num += sk * (double)eps[k];
-        den += sk;
+#pragma unroll
+        for (int j = 0; j < NV; j++) acc[j] += sk * (double)eps[(size_t)j * K + k];
+        acc[NV] += sk;
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { num += shfl_xor_d(num, m); den += shfl_xor_d(den, m); }
-    if (lane == 0) s_v[wave] = num;
+    for (int j = 0; j <= NV; j++) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[j] += shfl_xor_d(acc[j], m);
+        if (lane == 0) s_v[wave][j] = acc[j];
+    }
     __syncthreads();
-    const double n = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
+    if (tid <= NV) {
+        double tot = 0.0;
+        for (int w = 0; w < nwaves; w++) tot += s_v[w][tid];
+        s_v[0][tid] = tot;                 // only thread tid reads column tid of the other rows
+    }
     __syncthreads();
-    if (lane == 0) s_v[wave] = den;
-    __syncthreads();
-    if (tid == 0) {
-        const double d = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
-        base[hm] = (base[hm] * d + n) / (d + 1e-6);
-        part[3 + hm] = n;
-        if (hm == 0) {
-            part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
-            result[0] = bv; result[1] = (double)(k_offset + bi);
-        }
+    const double d = s_v[0][NV];
+    if (tid < NV) {
+        const double n = s_v[0][tid];
+        base[tid] = (base[tid] * d + n) / (d + 1e-6);
+        part[3 + t * NV + tid] = n;
+    }
+    if (t == 0 && tid == 0) {
+        part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
+        result[0] = bv; result[1] = (double)(k_offset + bi);
     }
 }
 
@@ -606,6 +617,8 @@ struct ModelOps {
                           const double* mean, double* log, int log_cap, int* log_count, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
     hipError_t (*critic)(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t);
+    hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, double* base,
+                              double* part, double* result, hipStream_t);
 };
 
 static bool near(double a, double b) { return std::fabs(a - b) <= 1e-12 * (1.0 + std::fabs(b)); }
@@ -719,9 +732,19 @@ static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int d
         hipLaunchKernelGGL((critic_kernel<double, MD::NV>), grid, block, 0, s, (const double*)fobs, K, dim, W1, b1, W2, b2, W3, g_last, (double*)R);
     return hipGetLastError();
 }
+template <class MD>
+static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset,
+                                     double* base, double* part, double* result, hipStream_t s) {
+    const dim3 grid(H, P), block(K > 1024 ? 1024 : 256);
+    if (dtype == MPPI_F32)
+        hipLaunchKernelGGL((update_rows_kernel<float, MD::NV>), grid, block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, base, part, result);
+    else
+        hipLaunchKernelGGL((update_rows_kernel<double, MD::NV>), grid, block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, base, part, result);
+    return hipGetLastError();
+}
 template <class MD> static ModelOps make_ops() {
     return {MD::name, MD::NV, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
-            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>};
+            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_update_rows<MD>};
 }
 static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>()};
 
@@ -1063,13 +1086,8 @@ static int launch_partials(mppi_planner* p, hipStream_t s) {
 }
 
 static int launch_update_fused(mppi_planner* p, hipStream_t s) {
-    if (p->cfg.dtype == MPPI_F32)
-        hipLaunchKernelGGL((update_fused_kernel<float>), dim3(p->HM, p->P), dim3(256), 0, s, (const float*)p->d_R, (const float*)p->d_eps,
-                           p->cfg.K, p->cfg.kappa, p->cfg.k_offset, p->d_base, p->d_part, p->d_result);
-    else
-        hipLaunchKernelGGL((update_fused_kernel<double>), dim3(p->HM, p->P), dim3(256), 0, s, (const double*)p->d_R, (const double*)p->d_eps,
-                           p->cfg.K, p->cfg.kappa, p->cfg.k_offset, p->d_base, p->d_part, p->d_result);
-    HIP_OK(hipGetLastError());
+    HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset,
+                                      p->d_base, p->d_part, p->d_result, s));
     return 0;
 }
 

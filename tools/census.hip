@@ -1,4 +1,7 @@
-// Instruction census of the pieces of the per-sample step (compile with -S and count).
+// Instruction census of the pieces of the per-sample step: compile with -S and count per kernel
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only -fno-slp-vectorize -S --cuda-device-only -o /tmp/census.s tools/census.hip
+//   python tools/isa_count.py /tmp/census.s c_
+// (each kernel's count includes its loads and stores of the inputs and outputs)
 #include <hip/hip_runtime.h>
 #include "../trajopt_amd/csrc/env_core.hpp"
 #include "../trajopt_amd/csrc/models_gen.hpp"
@@ -6,38 +9,71 @@ using namespace mppi;
 using MD = Reacher7Dof;
 using S = Step<float, MD>;
 constexpr int NV = MD::NV;
+#define IN(n) in[(n) * 64 + threadIdx.x]
+#define OUT(n) out[(n) * 64 + threadIdx.x]
 
+__global__ void __launch_bounds__(64) c_io_only(const float* in, float* out) {
+    static_for<3 * NV>([&](auto I) { OUT(I) = IN(I); });
+}
 __global__ void __launch_bounds__(64) c_trig(const float* in, float* out) {
-    float cs[NV], sn[NV];
-    static_for<NV>([&](auto I) { sincos_t(in[I * 64 + threadIdx.x], sn[I], cs[I]); });
-    static_for<NV>([&](auto I) { out[I * 64 + threadIdx.x] = cs[I]; out[(NV + I) * 64 + threadIdx.x] = sn[I]; });
+    float q[NV], cs[NV], sn[NV];
+    static_for<NV>([&](auto I) { q[I] = IN(I); });
+    S::trig(q, cs, sn);
+    static_for<NV>([&](auto I) { OUT(I) = cs[I]; OUT(NV + I) = sn[I]; });
 }
-__global__ void __launch_bounds__(64) c_bias(const float* in, float* out) {
-    float cs[NV], sn[NV], qd[NV], b[NV];
-    static_for<NV>([&](auto I) { cs[I] = in[I * 64 + threadIdx.x]; sn[I] = in[(NV + I) * 64 + threadIdx.x]; qd[I] = in[(2 * NV + I) * 64 + threadIdx.x]; });
-    S::bias_forces(cs, sn, qd, b);
-    static_for<NV>([&](auto I) { out[I * 64 + threadIdx.x] = b[I]; });
+__global__ void __launch_bounds__(64) c_smooth_force(const float* in, float* out) {
+    float q[NV], cs[NV], sn[NV], qd[NV], u[NV], fs[NV];
+    static_for<NV>([&](auto I) { q[I] = 0; cs[I] = IN(I); sn[I] = IN(NV + I); qd[I] = IN(2 * NV + I); u[I] = IN(3 * NV + I); });
+    S::smooth_force(q, cs, sn, qd, u, fs);
+    static_for<NV>([&](auto I) { OUT(I) = fs[I]; });
 }
-__global__ void __launch_bounds__(64) c_mass(const float* in, float* out) {
-    float cs[NV], sn[NV], M[NV][NV];
-    static_for<NV>([&](auto I) { cs[I] = in[I * 64 + threadIdx.x]; sn[I] = in[(NV + I) * 64 + threadIdx.x]; });
-    S::mass_matrix(cs, sn, M);
-    static_for<NV>([&](auto I) { static_for<I + 1>([&](auto J) { out[(I * NV + J) * 64 + threadIdx.x] = M[I][J]; }); });
+__global__ void __launch_bounds__(64) c_mass_matrix(const float* in, float* out) {
+    float q[NV], cs[NV], sn[NV], M[NV][NV];
+    static_for<NV>([&](auto I) { q[I] = 0; cs[I] = IN(I); sn[I] = IN(NV + I); });
+    S::mass_matrix(q, cs, sn, M);
+    static_for<NV>([&](auto I) { static_for<I + 1>([&](auto J) { OUT(I * NV + J) = M[I][J]; }); });
 }
-__global__ void __launch_bounds__(64) c_chol(const float* in, float* out) {
-    float A[NV][NV], b[NV];
-    static_for<NV>([&](auto I) { b[I] = in[(49 + I) * 64 + threadIdx.x]; static_for<I + 1>([&](auto J) { A[I][J] = in[(I * NV + J) * 64 + threadIdx.x]; }); });
-    float dg[NV];
-    static_for<NV>([&](auto I) { dg[I] = in[(60 + I) * 64 + threadIdx.x]; });
+__global__ void __launch_bounds__(64) c_build_rows(const float* in, float* out) {
+    float q[NV], cs[NV], sn[NV], qd[NV];
+    static_for<NV>([&](auto I) { q[I] = IN(3 * NV + I); cs[I] = IN(I); sn[I] = IN(NV + I); qd[I] = IN(2 * NV + I); });
+    typename S::Rows r;
+    S::build_rows(q, cs, sn, qd, r);
+    static_for<NV>([&](auto I) { OUT(I) = r.Dl[I]; OUT(NV + I) = r.arl[I]; OUT(2 * NV + I) = r.sg[I]; OUT(3 * NV + I) = r.Jc[I]; });
+    OUT(4 * NV) = r.Dc + r.arc + (r.any ? 1.f : 0.f);
+}
+__global__ void __launch_bounds__(64) c_hand_site(const float* in, float* out) {
+    float q[NV], cs[NV], sn[NV];
+    static_for<NV>([&](auto I) { q[I] = 0; cs[I] = IN(I); sn[I] = IN(NV + I); });
+    const Vec3<float> h = S::hand_site(q, cs, sn);
+    OUT(0) = h.v[0]; OUT(1) = h.v[1]; OUT(2) = h.v[2];
+}
+__global__ void __launch_bounds__(64) c_chol_solve(const float* in, float* out) {
+    float A[NV][NV], b[NV], dg[NV];
+    static_for<NV>([&](auto I) { b[I] = IN(49 + I); dg[I] = IN(60 + I); static_for<I + 1>([&](auto J) { A[I][J] = IN(I * NV + J); }); });
     S::chol_solve<false>(A, dg, 0.f, dg, b);
-    static_for<NV>([&](auto I) { out[I * 64 + threadIdx.x] = b[I]; });
+    static_for<NV>([&](auto I) { OUT(I) = b[I]; });
+}
+__global__ void __launch_bounds__(64) c_chol_solve_and_factor(const float* in, float* out) {
+    float A[NV][NV], b[NV], dg[NV], d2[NV];
+    static_for<NV>([&](auto I) { b[I] = IN(49 + I); dg[I] = IN(60 + I); d2[I] = IN(70 + I); static_for<I + 1>([&](auto J) { A[I][J] = IN(I * NV + J); }); });
+    typename S::DampedFactor f;
+    S::chol_solve_and_factor<false>(A, dg, 0.f, dg, b, d2, f.L, f.inv);
+    static_for<NV>([&](auto I) { OUT(I) = b[I]; OUT(NV + I) = f.inv[I]; static_for<I>([&](auto J) { OUT(20 + I * NV + J) = f.L[I][J]; }); });
+}
+__global__ void __launch_bounds__(64) c_integrate(const float* in, float* out) {
+    typename S::DampedFactor f;
+    float fs[NV], fc[NV], q[NV], qd[NV];
+    static_for<NV>([&](auto I) { fs[I] = IN(I); fc[I] = IN(NV + I); q[I] = IN(2 * NV + I); qd[I] = IN(3 * NV + I); f.inv[I] = IN(4 * NV + I);
+                                 static_for<I>([&](auto J) { f.L[I][J] = IN(40 + I * NV + J); }); });
+    S::integrate(f, fs, fc, q, qd);
+    static_for<NV>([&](auto I) { OUT(I) = q[I]; OUT(NV + I) = qd[I]; });
 }
 __global__ void __launch_bounds__(64) c_substep(const float* in, float* out) {
     float q[NV], v[NV], a[NV];
-    static_for<NV>([&](auto I) { q[I] = in[I * 64 + threadIdx.x]; v[I] = in[(NV + I) * 64 + threadIdx.x]; a[I] = in[(2 * NV + I) * 64 + threadIdx.x]; });
+    static_for<NV>([&](auto I) { q[I] = IN(I); v[I] = IN(NV + I); a[I] = IN(2 * NV + I); });
     typename S::Out o; o.hand = {{0, 0, 0}};
     unsigned am = ~0u; int sw;
     S::substep(q, v, a, in[0] > 0, o, am, sw);
-    static_for<NV>([&](auto I) { out[I * 64 + threadIdx.x] = q[I]; out[(NV + I) * 64 + threadIdx.x] = v[I]; });
-    out[1000 + threadIdx.x] = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am;
+    static_for<NV>([&](auto I) { OUT(I) = q[I]; OUT(NV + I) = v[I]; });
+    OUT(1000) = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am;
 }

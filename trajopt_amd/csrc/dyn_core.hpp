@@ -225,24 +225,49 @@ template <class T, class MD> struct Step {
 
     static MPPI_HD void build_rows(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], Rows& r) {
         r.any = false;
+        // joint limits: at most one side can be violated; evaluated without branches.  A row deeper than
+        // the impedance ramp (solimp width) has the constant impedance dmax, so its weight is a constant of
+        // the model and its reference acceleration two multiply-adds; only when some lane of the wave has a
+        // row inside the ramp is the impedance polynomial evaluated (same values either way).
+        T pos[NV];
+        bool ramp = false;
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
-            r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1);
+            r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1); pos[i] = T(0);
             if constexpr (MD::limited[i] != 0) {
-                // at most one side can be violated; evaluated without branches
                 const T lo = q[i] - T(MD::range_lo[i]);
                 const T hi = T(MD::range_hi[i]) - q[i];
                 const bool blo = lo < hi;
-                const T pos = blo ? lo : hi;
+                pos[i] = blo ? lo : hi;
                 r.sg[i] = blo ? T(1) : T(-1);
-                T D, ar;
-                row_constants(pos, r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
-                const bool on = pos < T(0);
-                r.Dl[i] = on ? D : T(0);
-                r.arl[i] = on ? ar : T(0);
-                r.any |= on;
+                r.any |= pos[i] < T(0);
+                ramp |= (pos[i] < T(0)) && (pos[i] > T(-MD::solimp[2]));
             }
         });
+        if (wave_any(ramp)) {
+            static_for<NV>([&](auto Ic) {
+                constexpr int i = Ic;
+                if constexpr (MD::limited[i] != 0) {
+                    T D, ar;
+                    row_constants(pos[i], r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
+                    const bool on = pos[i] < T(0);
+                    r.Dl[i] = on ? D : T(0);
+                    r.arl[i] = on ? ar : T(0);
+                }
+            });
+        } else {
+            static_for<NV>([&](auto Ic) {
+                constexpr int i = Ic;
+                if constexpr (MD::limited[i] != 0) {
+                    const T imp = T(MD::solimp[1]);
+                    const T D = imp * rcp_t((T(1) - imp) * T(MD::dof_invweight[i]));      // folds to a constant
+                    const T ar = -T(MD::solref_b) * (r.sg[i] * qd[i]) - T(MD::solref_k) * imp * pos[i];
+                    const bool on = pos[i] < T(0);
+                    r.Dl[i] = on ? D : T(0);
+                    r.arl[i] = on ? ar : T(0);
+                }
+            });
+        }
         r.Dc = T(0); r.arc = T(0);
         static_for<NV>([&](auto Ic) { r.Jc[Ic] = T(0); });
         if constexpr (MD::contact_link >= 0) {

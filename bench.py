@@ -123,13 +123,21 @@ def main():
     import torch.distributed as dist
     from trajopt_amd.device import DeviceModel, DevicePlanner
 
+    # MPPI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices round-robin; the exchange goes through host memory); the measured configuration is RCCL ("nccl")
+    backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     # MPPI_BENCH_SHARDED=1 exercises the sharded code path (partials, all-gather, merge) on one rank
     sharded = world > 1 or os.environ.get("MPPI_BENCH_SHARDED") == "1"
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     dm = DeviceModel.get("reacher_7dof")
     p = DevicePlanner(dm, K_PER_GPU, H, kappa=KAPPA, gamma=GAMMA, sigma=FILTER[0], betas=FILTER[1:],
@@ -155,7 +163,10 @@ def main():
             p.iterate(1, sptr)                       # rollouts + fused update
         else:
             p.local_partials(sptr)
-            dist.all_gather_into_tensor(gathered, part)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, part)
+            else:
+                dist.all_gather(list(gathered.view(world, -1).unbind(0)), part)
             p.merge(gathered.data_ptr(), world, sptr)
         p.advance(sptr)                              # real env fp64 step with act_sequence[0], log, horizon shift
 
@@ -177,7 +188,7 @@ def main():
     kernel_ms, launches = p.profile_read()
     p.profile(False)
     if sharded:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -17,7 +17,8 @@ static void run(const double* q0, const double* v0, const double* target, const 
     for (int c = 0; c < 3; c++) rp.target[c] = T(target[c]);
     T R = 0, g = 1;
     int ms = 0;
-    unsigned am = ~0u;
+    typename Step<T, MD>::Active am;
+    am.reset();
     Vec3<T> hand = {{0, 0, 0}};
     for (int t = 0; t < H; t++) {
         T a[NV];
@@ -42,3 +43,4 @@ extern "C" void core_rollout(int f64, int model, const double* q0, const double*
     else if (model == 1) { if (f64) GO(double, Reacher7DofFree); else GO(float, Reacher7DofFree); }
     else                 { if (f64) GO(double, Tree18Dof); else GO(float, Tree18Dof); }
 }
+

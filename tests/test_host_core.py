@@ -102,3 +102,4 @@ def test_tree_model_slides_and_gravity(core):
     assert np.abs(hand - nobs_o[0, -1, 36:39]).max() < 1e-10
     q, v, _, _, R32, _ = core(0, q0, v0, tgt, act, gamma=0.99, model=2)
     assert (np.abs(np.r_[q, v] - nobs_o[0, -1, :36]) / (1 + np.abs(nobs_o[0, -1, :36]))).max() < 2e-3
+

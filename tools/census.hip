@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(64) c_substep(const float* in, float* out) {
     float q[NV], v[NV], a[NV];
     static_for<NV>([&](auto I) { q[I] = IN(I); v[I] = IN(NV + I); a[I] = IN(2 * NV + I); });
     typename S::Out o; o.hand = {{0, 0, 0}};
-    unsigned am = ~0u; int sw;
+    typename S::Active am; am.reset(); int sw;
     S::substep(q, v, a, in[0] > 0, o, am, sw);
     static_for<NV>([&](auto I) { OUT(I) = q[I]; OUT(NV + I) = v[I]; });
-    OUT(1000) = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am;
+    OUT(1000) = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am.row[0] + am.row[NV];
 }

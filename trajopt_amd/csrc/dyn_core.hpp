@@ -75,6 +75,13 @@ MPPI_HD double rcp_t(double x) { return 1.0 / x; }
 MPPI_HD float abs_t(float x) { return fabsf(x); }
 MPPI_HD double abs_t(double x) { return fabs(x); }
 
+// Conditions on a sample are consumed with sel() (a select, never a branch): the per-sample code stays
+// one straight instruction stream whatever the lanes of a wave decide.
+template <class T> using Mask = bool;
+MPPI_HD float sel(bool c, float x, float y) { return c ? x : y; }
+MPPI_HD double sel(bool c, double x, double y) { return c ? x : y; }
+MPPI_HD bool any_of(bool c) { return c; }
+
 // true if the predicate holds on any active lane of the wave (host: the lane itself)
 MPPI_HD bool wave_any(bool x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -182,7 +189,14 @@ template <class T, class MD> struct Step {
     struct Rows {
         T Dl[NV], arl[NV], sg[NV];   // limit rows: weight (0 = no row), reference acceleration, sign of J
         T Jc[NV], Dc, arc;           // contact row: Jacobian, weight (0 = no row), reference acceleration
-        bool any;
+        Mask<T> any;
+    };
+    // Which rows were active at the end of the previous substep, as 1 / 0 ([i]: limit row of joint i,
+    // [NV]: contact row).  Carried through a rollout as the starting guess of the active-set solve;
+    // rows that do not exist count as active, so that they start active when they next appear.
+    struct Active {
+        T row[NV + 1];
+        MPPI_HD void reset() { static_for<NV + 1>([&](auto Ic) { row[Ic] = T(1); }); }
     };
 
     static MPPI_HD void trig(const T (&q)[NV], T (&cs)[NV], T (&sn)[NV]) {
@@ -217,31 +231,31 @@ template <class T, class MD> struct Step {
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             T u = ctrl[i];
-            u = u < T(MD::ctrl_lo[i]) ? T(MD::ctrl_lo[i]) : u;
-            u = u > T(MD::ctrl_hi[i]) ? T(MD::ctrl_hi[i]) : u;
+            u = sel(u < T(MD::ctrl_lo[i]), T(MD::ctrl_lo[i]), u);
+            u = sel(u > T(MD::ctrl_hi[i]), T(MD::ctrl_hi[i]), u);
             fs[i] = T(MD::gear[i]) * u - T(MD::damping[i]) * qd[i] - bias[i];
         });
     }
 
     static MPPI_HD void build_rows(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], Rows& r) {
-        r.any = false;
+        r.any = Mask<T>{};
         // joint limits: at most one side can be violated; evaluated without branches.  A row deeper than
         // the impedance ramp (solimp width) has the constant impedance dmax, so its weight is a constant of
         // the model and its reference acceleration two multiply-adds; only when some lane of the wave has a
         // row inside the ramp is the impedance polynomial evaluated (same values either way).
         T pos[NV];
-        bool ramp = false;
+        Mask<T> ramp{};
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1); pos[i] = T(0);
             if constexpr (MD::limited[i] != 0) {
                 const T lo = q[i] - T(MD::range_lo[i]);
                 const T hi = T(MD::range_hi[i]) - q[i];
-                const bool blo = lo < hi;
-                pos[i] = blo ? lo : hi;
-                r.sg[i] = blo ? T(1) : T(-1);
+                const Mask<T> blo = lo < hi;
+                pos[i] = sel(blo, lo, hi);
+                r.sg[i] = sel(blo, T(1), T(-1));
                 r.any |= pos[i] < T(0);
-                ramp |= (pos[i] < T(0)) && (pos[i] > T(-MD::solimp[2]));
+                ramp |= (pos[i] < T(0)) & (pos[i] > T(-MD::solimp[2]));
             }
         });
         if (wave_any(ramp)) {
@@ -250,9 +264,9 @@ template <class T, class MD> struct Step {
                 if constexpr (MD::limited[i] != 0) {
                     T D, ar;
                     row_constants(pos[i], r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
-                    const bool on = pos[i] < T(0);
-                    r.Dl[i] = on ? D : T(0);
-                    r.arl[i] = on ? ar : T(0);
+                    const Mask<T> on = pos[i] < T(0);
+                    r.Dl[i] = sel(on, D, T(0));
+                    r.arl[i] = sel(on, ar, T(0));
                 }
             });
         } else {
@@ -262,9 +276,9 @@ template <class T, class MD> struct Step {
                     const T imp = T(MD::solimp[1]);
                     const T D = imp * rcp_t((T(1) - imp) * T(MD::dof_invweight[i]));      // folds to a constant
                     const T ar = -T(MD::solref_b) * (r.sg[i] * qd[i]) - T(MD::solref_k) * imp * pos[i];
-                    const bool on = pos[i] < T(0);
-                    r.Dl[i] = on ? D : T(0);
-                    r.arl[i] = on ? ar : T(0);
+                    const Mask<T> on = pos[i] < T(0);
+                    r.Dl[i] = sel(on, D, T(0));
+                    r.arl[i] = sel(on, ar, T(0));
                 }
             });
         }
@@ -275,7 +289,8 @@ template <class T, class MD> struct Step {
             Vec3<T> xc[NV];
             const Vec3<T> cw = point_to_world<L>(q, cs, sn, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
             const T dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
-            if (dist < T(MD::contact_margin)) {
+            const Mask<T> near = dist < T(MD::contact_margin);
+            if (any_of(near)) {
                 // d(z of the sphere centre)/dq_i = z_i . (axis_i x x_i): world z axis and the point, both in link-i coordinates
                 Vec3<T> zl[NV];
                 T vel = T(0);
@@ -290,12 +305,15 @@ template <class T, class MD> struct Step {
                         else zp = zl[p];
                         zl[i] = to_child<A>(cs[i], sn[i], zp);
                         // (e_A x x)[U] = -x[W], (e_A x x)[W] = x[U]
-                        r.Jc[i] = T(MD::axis_sign[i]) * (zl[i].v[W] * xc[i].v[U] - zl[i].v[U] * xc[i].v[W]);
+                        r.Jc[i] = sel(near, T(MD::axis_sign[i]) * (zl[i].v[W] * xc[i].v[U] - zl[i].v[U] * xc[i].v[W]), T(0));
                         vel += r.Jc[i] * qd[i];
                     }
                 });
-                row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), r.Dc, r.arc);
-                r.any = true;
+                T Dc, arc;
+                row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), Dc, arc);
+                r.Dc = sel(near, Dc, T(0));
+                r.arc = sel(near, arc, T(0));
+                r.any |= near;
             }
         }
     }
@@ -310,22 +328,22 @@ template <class T, class MD> struct Step {
     }
 
     // exact active-set solve of the soft constraint rows: fc = J^T f with f >= 0 on the active rows.
-    //   act_mask : active rows carried from the previous substep (bit i: limit row of joint i, bit NV:
-    //              contact row); start a rollout with all bits set.  The iteration converges to the same
-    //              unique solution from any start; starting from the previous set usually needs one sweep.
+    //   act      : active rows carried from the previous substep; reset() at the start of a rollout.  The
+    //              iteration converges to the same unique solution from any start; starting from the
+    //              previous set usually needs one sweep.
     //   damped   : receives the factor of M + h B, which integrate() needs afterwards; it is computed
     //              inside the first sweep, column by column next to the constraint system's own factor
     //              (two independent chains keep a lone wave's pipeline busy).
     // The loop is uniform over the wave: lanes whose set has settled repeat the same solve (same result)
     // until every lane has settled, so the only cross-lane operation is one vote per sweep.
-    static MPPI_HD void constraint_forces(const T (&M)[NV][NV], const T (&fs)[NV], const Rows& r, unsigned& act_mask,
+    static MPPI_HD void constraint_forces(const T (&M)[NV][NV], const T (&fs)[NV], const Rows& r, Active& act,
                                           T (&fc)[NV], int& sweeps_out, DampedFactor& damped) {
         static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
         int sweeps = 0;
         if (wave_any(r.any)) {
             // active weight of every row: its D while active, 0 while inactive or absent
-            T dg[NV], dc = ((act_mask >> NV) & 1u) ? r.Dc : T(0);
-            static_for<NV>([&](auto Ic) { dg[Ic] = ((act_mask >> Ic) & 1u) ? r.Dl[Ic] : T(0); });
+            T dg[NV], dc = act.row[NV] * r.Dc;
+            static_for<NV>([&](auto Ic) { dg[Ic] = act.row[Ic] * r.Dl[Ic]; });
             T acc[NV], resl[NV], resc = T(0);
             const bool wave_contact = wave_any(r.Dc > T(0));
             auto right_hand_side = [&]() {
@@ -333,13 +351,13 @@ template <class T, class MD> struct Step {
                 if (wave_contact) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
             };
             // residual signs decide the next active set; true if this lane's set changed
-            auto settle = [&]() -> bool {
-                bool changed = false;
+            auto settle = [&]() -> Mask<T> {
+                Mask<T> changed{};
                 static_for<NV>([&](auto Ic) {
                     constexpr int i = Ic;
                     if constexpr (MD::limited[i] != 0) {
                         resl[i] = r.sg[i] * acc[i] - r.arl[i];
-                        const T nd = (resl[i] < T(0)) ? r.Dl[i] : T(0);
+                        const T nd = sel(resl[i] < T(0), r.Dl[i], T(0));
                         changed |= (nd != dg[i]);
                         dg[i] = nd;
                     }
@@ -348,7 +366,7 @@ template <class T, class MD> struct Step {
                     T ja = T(0);
                     static_for<NV>([&](auto Ic) { ja += r.Jc[Ic] * acc[Ic]; });
                     resc = ja - r.arc;
-                    const T nd = (resc < T(0)) ? r.Dc : T(0);
+                    const T nd = sel(resc < T(0), r.Dc, T(0));
                     changed |= (nd != dc);
                     dc = nd;
                 }
@@ -360,7 +378,7 @@ template <class T, class MD> struct Step {
             static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::H * MD::damping[Ic]); });
             if (wave_contact) chol_solve_and_factor<true>(M, dg, dc, r.Jc, acc, hb, damped.L, damped.inv);
             else chol_solve_and_factor<false>(M, dg, T(0), r.Jc, acc, hb, damped.L, damped.inv);
-            bool changed = settle();
+            Mask<T> changed = settle();
             while (wave_any(changed) && sweeps < 12) {
                 sweeps++;
                 right_hand_side();
@@ -377,12 +395,10 @@ template <class T, class MD> struct Step {
                 static_for<NV>([&](auto Ic) { fc[Ic] += r.Jc[Ic] * f; });
             }
             // rows that do not exist start active when they next appear
-            unsigned m = 0u;
-            static_for<NV>([&](auto Ic) { m |= ((r.Dl[Ic] > T(0)) && !(dg[Ic] > T(0))) ? 0u : (1u << Ic); });
-            m |= ((r.Dc > T(0)) && !(dc > T(0))) ? 0u : (1u << NV);
-            act_mask = m;
+            static_for<NV>([&](auto Ic) { act.row[Ic] = sel((r.Dl[Ic] > T(0)) & !(dg[Ic] > T(0)), T(0), T(1)); });
+            act.row[NV] = sel((r.Dc > T(0)) & !(dc > T(0)), T(0), T(1));
         } else {
-            act_mask = ~0u;
+            act.reset();
             factor_damped(M, damped);
         }
         sweeps_out = sweeps;
@@ -402,9 +418,9 @@ template <class T, class MD> struct Step {
 
     // (q, v, ctrl) -> (q', v') in place.
     //   want_hand : also evaluate the end-effector site at the input q
-    //   act_mask  : see constraint_forces
+    //   act       : see constraint_forces
     static MPPI_HD void substep(T (&q)[NV], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
-                                unsigned& act_mask, int& sweeps_out) {
+                                Active& act, int& sweeps_out) {
         T cs[NV], sn[NV];
         trig(q, cs, sn);
         if constexpr (MD::hand_link >= 0) {
@@ -418,7 +434,7 @@ template <class T, class MD> struct Step {
         build_rows(q, cs, sn, qd, rows);
         DampedFactor f;
         T fc[NV];
-        constraint_forces(M, fs, rows, act_mask, fc, sweeps_out, f);
+        constraint_forces(M, fs, rows, act, fc, sweeps_out, f);
         integrate(f, fs, fc, q, qd);
     }
 
@@ -511,7 +527,7 @@ template <class T, class MD> struct Step {
             // column i of M: force produced by unit acceleration of joint i on composite body i
             {
                 Vec3<T> ea = {{T(0), T(0), T(0)}};
-                constexpr T sgn = T(MD::axis_sign[i]);
+                const T sgn = T(MD::axis_sign[i]);
                 ea.v[A] = sgn;
                 Vec3<T> n, f;
                 if constexpr (MD::jtype[i] == 1) {
@@ -586,8 +602,8 @@ template <class T, class MD> struct Step {
         const T w = T(1) - u;
         const T ylo = u * u * T(1.0 / MD::solimp[3]);
         const T yhi = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3]));
-        const T y = (u <= mid) ? ylo : yhi;
-        const T imp = (u < T(1)) ? d0 + y * (dmax - d0) : dmax;
+        const T y = sel(u <= mid, ylo, yhi);
+        const T imp = sel(u < T(1), d0 + y * (dmax - d0), dmax);
         aref = -T(MD::solref_b) * vel - T(MD::solref_k) * imp * x;
         D = imp * rcp_t((T(1) - imp) * invweight);
     }

@@ -25,9 +25,9 @@ template <class T> struct RewardParams {
 // function of its own it matches the fp64 oracle to rounding.  fp32 stays inline.
 template <class MD>
 __device__ __noinline__ void substep_outofline(double (&q)[MD::NV], double (&qd)[MD::NV], const double (&act)[MD::NV],
-                                               bool want_hand, typename Step<double, MD>::Out& o, unsigned& act_mask,
-                                               int& sw) {
-    Step<double, MD>::substep(q, qd, act, want_hand, o, act_mask, sw);
+                                               bool want_hand, typename Step<double, MD>::Out& o,
+                                               typename Step<double, MD>::Active& rows, int& sw) {
+    Step<double, MD>::substep(q, qd, act, want_hand, o, rows, sw);
 }
 #endif
 
@@ -42,7 +42,7 @@ template <class T, class MD> struct Env {
         const T vn = sqrt_t(vv);
         const T dx = hand.v[0] - rp.target[0], dy = hand.v[1] - rp.target[1], dz = hand.v[2] - rp.target[2];
         const T dist = sqrt_t(dx * dx + dy * dy + dz * dz);
-        const T sparse = dist < T(0.025) ? T(100) : (dist > T(0.8) ? T(-100) : T(-10));
+        const T sparse = sel(dist < T(0.025), T(100), sel(dist > T(0.8), T(-100), T(-10)));
         if (rp.type == REWARD_SPARSE) return sparse;
         if (rp.type == REWARD_TRACKING || rp.type == REWARD_COOLING) {
             const T ex = hand.v[0] - ref_row[0], ey = hand.v[1] - ref_row[1], ez = hand.v[2] - ref_row[2];
@@ -54,7 +54,7 @@ template <class T, class MD> struct Env {
     }
 
     static MPPI_HD T step(T (&q)[NV], T (&qd)[NV], const T (&act)[NV], const RewardParams<T>& rp, const T* ref_row,
-                          Vec3<T>& hand, unsigned& act_mask, int& max_sweeps) {
+                          Vec3<T>& hand, typename S::Active& rows, int& max_sweeps) {
         typename S::Out o;
         o.hand = {{T(0), T(0), T(0)}};
 #if defined(__clang__)
@@ -63,10 +63,10 @@ template <class T, class MD> struct Env {
         for (int s = 0; s < MD::FRAME_SKIP; s++) {
             int sw;
 #if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (std::is_same<T, double>::value) substep_outofline<MD>(q, qd, act, s == MD::FRAME_SKIP - 1, o, act_mask, sw);
-            else S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, act_mask, sw);
+            if constexpr (std::is_same<T, double>::value) substep_outofline<MD>(q, qd, act, s == MD::FRAME_SKIP - 1, o, rows, sw);
+            else S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, rows, sw);
 #else
-            S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, act_mask, sw);
+            S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, rows, sw);
 #endif
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
         }

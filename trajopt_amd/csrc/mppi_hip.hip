@@ -200,7 +200,8 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     const int t0 = st->timestep, ref_len = st->ref_len;
     const T gm = T(gamma);
     T ret = T(0), g = T(1);
-    unsigned act_mask = ~0u;
+    typename Step<T, MD>::Active act_rows;
+    act_rows.reset();
     // the next step's noise and base action are fetched one step ahead: they do not depend on the
     // state, and a lone wave has nobody to hide a load's latency behind
     T e_nx[NV];
@@ -223,7 +224,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         }
         Vec3<T> hand;
         int ms = 0;
-        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_mask, ms);
+        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_rows, ms);
         // with a terminal-value critic the last reward is replaced by the critic's value (added by critic_kernel)
         if (!(fobs && t == H - 1)) ret += g * r;
         g *= gm;
@@ -266,12 +267,14 @@ __global__ void __launch_bounds__(64) env_step_kernel(const double* __restrict__
         static_for<NV>([&](auto Ic) { q2[Ic] = q[Ic]; v2[Ic] = v[Ic]; z[Ic] = 0.0; });
         typename Step<double, MD>::Out o;
         int sw;
-        unsigned am = ~0u;
+        typename Step<double, MD>::Active am;
+        am.reset();
         Step<double, MD>::substep(q2, v2, z, true, o, am, sw);
         hand = o.hand;
     } else {
         int ms = 0;
-        unsigned am = ~0u;
+        typename Step<double, MD>::Active am;
+        am.reset();
         r = Env<double, MD>::step(q, v, a, rp, has_ref ? rr : nullptr, hand, am, ms);
     }
     static_for<NV>([&](auto Ic) { out[Ic] = q[Ic]; out[NV + Ic] = v[Ic]; out[2 * NV + Ic] = q[Ic]; out[3 * NV + Ic] = v[Ic]; });
@@ -323,7 +326,8 @@ __global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st,
         }
         Vec3<double> hand;
         int ms = 0;
-        unsigned am = ~0u;
+        typename Step<double, MD>::Active am;
+        am.reset();
         const double r = Env<double, MD>::step(q, v, a, rp, rr, hand, am, ms);
         const int n = *log_count;
         double* row = log + (size_t)(n % log_cap) * ROW;

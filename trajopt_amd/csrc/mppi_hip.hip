@@ -470,20 +470,21 @@ __global__ void __launch_bounds__(256) wsum_kernel(const double* __restrict__ S,
     if (tid == 0) part[3 + hm] = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
 }
 
-// Single-rank update in one launch, one block per (step t, planner): the block finds Rmax / first arg-max
-// itself (every block gets the same values, in the same fixed order), evaluates every weight
-// S_k = exp(kappa (R_k - Rmax)) once and accumulates sum S and the NV weighted sums of its step, then
-// writes act_sequence[t][:].  Any block size that is a multiple of 64 up to 1024.
-template <class T, int NV>
+// Single-rank update in one launch.  A block owns ROWS consecutive (step, action dimension) rows of one planner:
+// it finds Rmax / first arg-max itself (every block gets the same values, in the same fixed order), evaluates
+// every weight S_k = exp(kappa (R_k - Rmax)) once and accumulates sum S and its ROWS weighted sums, then writes
+// its entries of act_sequence.  ROWS = NV (one block per step) when there are many planners to fill the GPU,
+// ROWS = 1 (one block per entry) for a single planner.  Any block size that is a multiple of 64 up to 1024.
+template <class T, int NV, int ROWS>
 __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
-                                                           int k_offset, double* __restrict__ base, double* __restrict__ part,
+                                                           int k_offset, int HM, double* __restrict__ base, double* __restrict__ part,
                                                            double* __restrict__ result) {
-    __shared__ double s_v[16][NV + 1];
+    __shared__ double s_v[16][ROWS + 1];
     __shared__ int s_i[16];
-    const int t = blockIdx.x, H = gridDim.x, HM = H * NV, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + (size_t)t * NV) * K;
-    base += (size_t)blockIdx.y * HM + t * NV; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
+    R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + row0) * K;
+    base += (size_t)blockIdx.y * HM + row0; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
     double bv = -DBL_MAX;
     int bi = INT_MAX;
     for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
@@ -498,35 +499,35 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     bv = s_v[0][0]; bi = s_i[0];
     for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
     __syncthreads();
-    double acc[NV + 1];            // [NV]: sum of the weights
+    double acc[ROWS + 1];            // [ROWS]: sum of the weights
 #pragma unroll
-    for (int j = 0; j <= NV; j++) acc[j] = 0.0;
+    for (int j = 0; j <= ROWS; j++) acc[j] = 0.0;
     for (int k = tid; k < K; k += nthreads) {
         const double sk = exp(kappa * ((double)R[k] - bv));
 #pragma unroll
-        for (int j = 0; j < NV; j++) acc[j] += sk * (double)eps[(size_t)j * K + k];
-        acc[NV] += sk;
+        for (int j = 0; j < ROWS; j++) acc[j] += sk * (double)eps[(size_t)j * K + k];
+        acc[ROWS] += sk;
     }
 #pragma unroll
-    for (int j = 0; j <= NV; j++) {
+    for (int j = 0; j <= ROWS; j++) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) acc[j] += shfl_xor_d(acc[j], m);
         if (lane == 0) s_v[wave][j] = acc[j];
     }
     __syncthreads();
-    if (tid <= NV) {
+    if (tid <= ROWS) {
         double tot = 0.0;
         for (int w = 0; w < nwaves; w++) tot += s_v[w][tid];
         s_v[0][tid] = tot;                 // only thread tid reads column tid of the other rows
     }
     __syncthreads();
-    const double d = s_v[0][NV];
-    if (tid < NV) {
+    const double d = s_v[0][ROWS];
+    if (tid < ROWS) {
         const double n = s_v[0][tid];
         base[tid] = (base[tid] * d + n) / (d + 1e-6);
-        part[3 + t * NV + tid] = n;
+        part[3 + row0 + tid] = n;
     }
-    if (t == 0 && tid == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
         result[0] = bv; result[1] = (double)(k_offset + bi);
     }
@@ -739,11 +740,21 @@ static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int d
 template <class MD>
 static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset,
                                      double* base, double* part, double* result, hipStream_t s) {
-    const dim3 grid(H, P), block(K > 1024 ? 1024 : 256);
-    if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((update_rows_kernel<float, MD::NV>), grid, block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, base, part, result);
-    else
-        hipLaunchKernelGGL((update_rows_kernel<double, MD::NV>), grid, block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, base, part, result);
+    constexpr int NV = MD::NV;
+    const int HM = H * NV;
+    const dim3 block(K > 1024 ? 1024 : 256);
+    // enough blocks to spread over the GPU: one per step once there are many planners, else one per entry
+    if ((long)H * P >= 1024) {
+        if (dtype == MPPI_F32)
+            hipLaunchKernelGGL((update_rows_kernel<float, NV, NV>), dim3(H, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, base, part, result);
+        else
+            hipLaunchKernelGGL((update_rows_kernel<double, NV, NV>), dim3(H, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, base, part, result);
+    } else {
+        if (dtype == MPPI_F32)
+            hipLaunchKernelGGL((update_rows_kernel<float, NV, 1>), dim3(HM, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, base, part, result);
+        else
+            hipLaunchKernelGGL((update_rows_kernel<double, NV, 1>), dim3(HM, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, base, part, result);
+    }
     return hipGetLastError();
 }
 template <class MD> static ModelOps make_ops() {

@@ -158,7 +158,8 @@ def main():
         if not sharded and not profiling[0]:
             p.plan(SEED, 1, 1, sptr)                 # the same sequence as below, as one hipGraph replay
             return
-        p.generate_noise_step(SEED, sptr)            # Philox key = SEED + current timestep (read on the device)
+        # the Philox noise of this step (key = SEED + timestep, read on the device) was drawn by the previous
+        # step's advance launch, next to the real-env step; the first step draws its own below
         if not sharded:
             p.iterate(1, sptr)                       # rollouts + fused update
         else:
@@ -168,13 +169,15 @@ def main():
             else:
                 dist.all_gather(list(gathered.view(world, -1).unbind(0)), part)
             p.merge(gathered.data_ptr(), world, sptr)
-        p.advance(sptr)                              # real env fp64 step with act_sequence[0], log, horizon shift
+        p.advance_noise(SEED, sptr)                  # real env fp64 step with act_sequence[0], log, horizon shift,
+                                                     # and the next step's noise on the idle CUs of the same launch
 
     def barrier():
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
+    p.generate_noise_step(SEED, sptr)
     for _ in range(args.warmup):
         planning_step()
     p.profile(True)

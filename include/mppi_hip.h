@@ -173,8 +173,16 @@ int mppi_advance(mppi_planner* p, void* stream);
 /* nsteps whole planning steps -- the loop `for t: agent.train_step(niter)` of the example scripts
  * (sandbox/examples/reacher_7dof_mppi.py:49-50) -- enqueued as replays of one captured hipGraph:
  * Philox noise keyed by seed + timestep, niter x (rollouts, update), device-resident advance.
- * Nothing returns to the host until mppi_read_log / mppi_read. */
+ * Nothing returns to the host until mppi_read_log / mppi_read.  On handles of up to 65536 samples the
+ * noise of step t+1 is drawn in the advance launch of step t (see mppi_advance_noise); afterwards the
+ * noise buffer (MPPI_READ_ACTIONS) therefore belongs to the step that has not been planned yet. */
 int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream);
+/* mppi_advance and, in the same launch on otherwise idle CUs, mppi_generate_noise_step for the NEXT
+ * planning step (stream key seed + new timestep); must follow the rollouts of the current step.
+ * A loop  generate_noise_step; { iterate; advance_noise; }*  produces the same trajectory as
+ * { generate_noise_step; iterate; advance; }*.  No counterpart in the reference (its noise is drawn
+ * inside every worker, trajopt/utils.py:135-139). */
+int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream);
 int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
 
 int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);

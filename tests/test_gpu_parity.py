@@ -323,3 +323,44 @@ def test_whole_step_graph_equals_separate_calls(dev_model):
     assert np.array_equal(a.act_sequence(), b.act_sequence())
     a.plan(91, niter=niter, nsteps=2)              # replays the cached graph
     assert a.read_log()["total"] == steps + 2
+
+
+@pytest.mark.parametrize("planners", [1, 3])
+def test_noise_drawn_in_the_advance_launch_gives_the_same_trajectory(dev_model, planners):
+    """advance_noise (real-env step and the next step's Philox noise in one launch) against the separate calls, and
+    mppi_plan against both: identical real-env logs, bit for bit."""
+    K, H, steps, seed = 192, 12, 6, 31
+    rs = np.random.RandomState(8)
+    lead = (planners,) if planners > 1 else ()
+    tgt = rs.randn(*lead, 3) * 0.1
+    ps = [_planner(dev_model, K, H, "f32", gamma=0.97, planners=planners) for _ in range(3)]
+    for p in ps:
+        p.set_start_state(np.zeros(lead + (7,)), np.zeros(lead + (7,)), tgt, 2)
+        p.set_base_actions(np.zeros(lead + (H, 7)))
+    a, b, c = ps
+    for t in range(steps):
+        a.generate_noise_step(seed)
+        a.iterate(2)
+        a.advance()
+    b.generate_noise_step(seed)
+    for t in range(steps):
+        b.iterate(2)
+        b.advance_noise(seed)
+    c.plan(seed, niter=2, nsteps=2)
+    c.plan(seed, niter=2, nsteps=steps - 2)          # the second call finds its first step's noise already drawn
+    for pl in range(planners):
+        la, lb, lc = a.read_log(planner=pl), b.read_log(planner=pl), c.read_log(planner=pl)
+        assert la["total"] == lb["total"] == lc["total"] == steps
+        for key in ("qpos", "qvel", "hand", "reward", "action"):
+            assert np.array_equal(la[key], lb[key]), key
+            assert np.array_equal(la[key], lc[key]), key
+    assert np.array_equal(a.act_sequence(), b.act_sequence()) and np.array_equal(a.act_sequence(), c.act_sequence())
+    # a change of state between two plans invalidates nothing that matters: the noise key follows the new timestep
+    c.set_start_state(np.zeros(lead + (7,)), np.zeros(lead + (7,)), tgt, 40)
+    a.set_start_state(np.zeros(lead + (7,)), np.zeros(lead + (7,)), tgt, 40)
+    c.set_base_actions(np.zeros(lead + (H, 7))); a.set_base_actions(np.zeros(lead + (H, 7)))
+    c.plan(seed, niter=1, nsteps=1)
+    a.generate_noise_step(seed); a.iterate(1); a.advance()
+    assert np.array_equal(a.act_sequence(), c.act_sequence())
+    for p in ps:
+        p.close()

@@ -130,17 +130,14 @@ __global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restri
 // draws of steps 4c .. 4c+3.  With seed_from_state the stream key is seed + the planner's current
 // timestep (the reference re-seeds every planning step with seed + t, trajopt/algos/mppi.py:130-132)
 template <class T, int NV>
-__global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
-                                                           const DevState* __restrict__ st, int seed_from_state,
-                                                           FilterCoefs fc, T* __restrict__ eps) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void noise_philox_block(int block, int pl, int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
+                                                   int step, int seed_from_state, const FilterCoefs& fc, T* __restrict__ eps) {
+    const int idx = block * 256 + threadIdx.x;
     if (idx >= K * NV) return;
     const int j = idx / K, k = idx - j * K;
-    const int pl = blockIdx.y;                        // planner of a batched handle: its own counter plane
-    eps += (size_t)pl * H * NV * K;
-    st += pl;
+    eps += (size_t)pl * H * NV * K;                   // planner of a batched handle: its own counter plane
     if (seed_from_state) {
-        const uint64_t s = (((uint64_t)seed_hi << 32) | seed_lo) + (uint64_t)(int64_t)st->timestep;
+        const uint64_t s = (((uint64_t)seed_hi << 32) | seed_lo) + (uint64_t)(int64_t)step;
         seed_lo = (uint32_t)s;
         seed_hi = (uint32_t)(s >> 32);
     }
@@ -165,6 +162,12 @@ __global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_o
         }
     }
 }
+template <class T, int NV>
+__global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
+                                                           const DevState* __restrict__ st, int seed_from_state,
+                                                           FilterCoefs fc, T* __restrict__ eps) {
+    noise_philox_block<T, NV>(blockIdx.x, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, st[blockIdx.y].timestep, seed_from_state, fc, eps);
+}
 
 // ------------------------------------------------------------------------------------------
 // rollout
@@ -179,11 +182,13 @@ __global__ void __launch_bounds__(64)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
                const double* __restrict__ ref, int K, int H, int reward_type, double gamma, int explicit_act,
                T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status,
-               T* __restrict__ fobs) {
+               T* __restrict__ fobs, int* __restrict__ next_step) {
     constexpr int NV = MD::NV;
     constexpr int OD = 2 * NV + 6;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
+    // index of the planning step after this one, for a noise generator that runs while the state advances
+    if (k == 0) next_step[blockIdx.y] = st[blockIdx.y].timestep + 1;
     {   // planner blockIdx.y of a batched handle
         const size_t pl = blockIdx.y;
         st += pl; base += pl * H * NV; eps += pl * H * NV * K; R += pl * K;
@@ -287,18 +292,18 @@ __global__ void __launch_bounds__(64) env_step_kernel(const double* __restrict__
 // act_sequence[0] from the planner's own state, appends (q', v', hand, target, reward, action) to the log ring and
 // stores the new state; then the whole block shifts the horizon and fills the tail.
 template <class MD>
-__global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
-                                                      const double* __restrict__ ref, int reward_type, int H, int tail_mode,
-                                                      const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                                      int* __restrict__ log_count) {
+__device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st, double* __restrict__ base,
+                                              const double* __restrict__ ref, int reward_type, int H, int tail_mode,
+                                              const double* __restrict__ mean, double* __restrict__ log, int log_cap,
+                                              int* __restrict__ log_count) {
     constexpr int NV = MD::NV;
     constexpr int ROW = 3 * NV + 7;
     constexpr int PER = 16;                       // H * NV <= 256 * PER
     const int tid = threadIdx.x;
     double keep[PER];
     const int HM = H * NV;
-    st += blockIdx.x; base += (size_t)blockIdx.x * HM;           // one block per planner
-    log += (size_t)blockIdx.x * log_cap * ROW; log_count += blockIdx.x;
+    st += pl; base += (size_t)pl * HM;                           // one block per planner
+    log += (size_t)pl * log_cap * ROW; log_count += pl;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int i = tid + 256 * u;
@@ -344,6 +349,26 @@ __global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st,
         const int i = tid + 256 * u;
         if (i < HM) base[i] = keep[u];
     }
+}
+template <class MD>
+__global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
+                                                      const double* __restrict__ ref, int reward_type, int H, int tail_mode,
+                                                      const double* __restrict__ mean, double* __restrict__ log, int log_cap,
+                                                      int* __restrict__ log_count) {
+    advance_block<MD>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
+}
+// advance_kernel and, in the blocks behind the first of every planner, the Philox noise of the NEXT planning step
+// (stream key seed + next_step[planner], published by the rollouts of the current step): the noise does not depend
+// on the new state, so it is drawn on otherwise idle CUs while one lane steps the real environment.
+template <class T, class MD>
+__global__ void __launch_bounds__(256) advance_noise_kernel(DevState* __restrict__ st, double* __restrict__ base,
+                                                            const double* __restrict__ ref, int reward_type, int H, int tail_mode,
+                                                            const double* __restrict__ mean, double* __restrict__ log, int log_cap,
+                                                            int* __restrict__ log_count, int K, int k_offset, uint32_t seed_lo,
+                                                            uint32_t seed_hi, const int* __restrict__ next_step, FilterCoefs fc,
+                                                            T* __restrict__ eps) {
+    if (blockIdx.x == 0) advance_block<MD>(blockIdx.y, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
+    else noise_philox_block<T, MD::NV>(blockIdx.x - 1, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, next_step[blockIdx.y], 1, fc, eps);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -607,7 +632,7 @@ __global__ void __launch_bounds__(256) update_direct_kernel(const double* __rest
 struct RolloutArgs {
     const DevState* st; const double* base; const void* eps; const double* ref;
     int K, H, P, reward_type; double gamma; int explicit_act;
-    void* R; void* obs; void* rew; int* status; void* fobs;
+    void* R; void* obs; void* rew; int* status; void* fobs; int* next_step;
 };
 
 struct ModelOps {
@@ -622,6 +647,9 @@ struct ModelOps {
                           const double* mean, double* log, int log_cap, int* log_count, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
     hipError_t (*critic)(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t);
+    hipError_t (*advance_noise)(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
+                                const double* mean, double* log, int log_cap, int* log_count, int K, int k_offset, uint64_t seed,
+                                const int* next_step, const FilterCoefs& fc, void* eps, hipStream_t);
     hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, double* base,
                               double* part, double* result, hipStream_t);
 };
@@ -683,10 +711,10 @@ template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArg
     const dim3 grid((a.K + 63) / 64, a.P), block(64);      // one wave per block: waves spread over CUs and XCDs
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((rollout_kernel<float, MD>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs);
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step);
     else
         hipLaunchKernelGGL((rollout_kernel<double, MD>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs);
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs, a.next_step);
     return hipGetLastError();
 }
 template <class MD>
@@ -714,6 +742,21 @@ template <class MD>
 static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                  const double* mean, double* log, int log_cap, int* log_count, hipStream_t s) {
     hipLaunchKernelGGL((advance_kernel<MD>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
+    return hipGetLastError();
+}
+template <class MD>
+static hipError_t launch_advance_noise(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P,
+                                       int tail_mode, const double* mean, double* log, int log_cap, int* log_count, int K,
+                                       int k_offset, uint64_t seed, const int* next_step, const FilterCoefs& fc, void* eps,
+                                       hipStream_t s) {
+    const dim3 grid(1 + (K * MD::NV + 255) / 256, P), block(256);
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    if (dtype == MPPI_F32)
+        hipLaunchKernelGGL((advance_noise_kernel<float, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
+                           log_cap, log_count, K, k_offset, lo, hi, next_step, fc, (float*)eps);
+    else
+        hipLaunchKernelGGL((advance_noise_kernel<double, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
+                           log_cap, log_count, K, k_offset, lo, hi, next_step, fc, (double*)eps);
     return hipGetLastError();
 }
 template <class MD>
@@ -759,7 +802,7 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
 }
 template <class MD> static ModelOps make_ops() {
     return {MD::name, MD::NV, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
-            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_update_rows<MD>};
+            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_advance_noise<MD>, &launch_update_rows<MD>};
 }
 static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>()};
 
@@ -799,6 +842,9 @@ struct mppi_planner {
     int critic_dim;        // 0: no critic
     double* d_log;         // [LOG_CAP][3M+7] real-env log ring of mppi_advance
     int* d_log_count;
+    int* d_next_step;      // [P] index of the planning step after the one being rolled out
+    bool noise_ahead;      // eps already holds the Philox noise of the coming planning step ...
+    uint64_t noise_ahead_seed;   // ... drawn with this seed
     int explicit_act;
     FilterCoefs fc;
     hipGraphExec_t graph;
@@ -878,6 +924,8 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (3 * p->nv + 7) * 8));
     HIP_OK(hipMalloc(&p->d_log_count, 4 * P));
     HIP_OK(hipMemset(p->d_log_count, 0, 4 * P));
+    HIP_OK(hipMalloc(&p->d_next_step, 4 * P));
+    HIP_OK(hipMemset(p->d_next_step, 0, 4 * P));
     if (cfg->dump) {
         HIP_OK(hipMalloc(&p->d_obs, K * cfg->H * OD * p->esz));
         HIP_OK(hipMalloc(&p->d_rew, K * cfg->H * p->esz));
@@ -906,7 +954,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     if (p->step_graph) (void)hipGraphExecDestroy(p->step_graph);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
-                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic};
+                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     (void)hipStreamDestroy(p->stream);
@@ -926,6 +974,7 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
     }
     HIP_OK(hipMemcpyAsync(p->d_state, s.data(), sizeof(DevState) * p->P, hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
+    p->noise_ahead = false;          // the stream key follows the timestep
     return 0;
 }
 
@@ -1005,6 +1054,7 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) {
     HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 1, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));     // the host buffer may be reused by the caller
     p->explicit_act = 0;
+    p->noise_ahead = false;
     return 0;
 }
 
@@ -1014,6 +1064,7 @@ static int generate_noise(mppi_planner* p, uint64_t seed, int seed_from_state, v
     HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->P, p->cfg.k_offset, seed, p->d_state, seed_from_state,
                                        p->fc, p->d_eps, pick(p, stream)));
     p->explicit_act = 0;
+    p->noise_ahead = false;
     return 0;
 }
 int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream) { return generate_noise(p, seed, 0, stream); }
@@ -1025,6 +1076,19 @@ int mppi_advance(mppi_planner* p, void* stream) {
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
                                   p->d_log, MPPI_LOG_CAP, p->d_log_count, pick(p, stream)));
+    return 0;
+}
+
+int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) {
+    if (!p) return fail(-1, "null argument");
+    if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance_noise");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
+                                        p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->cfg.K,
+                                        p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps, pick(p, stream)));
+    p->explicit_act = 0;
+    p->noise_ahead = true;
+    p->noise_ahead_seed = seed;
     return 0;
 }
 
@@ -1058,6 +1122,7 @@ int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) {
     HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 0, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));
     p->explicit_act = 1;
+    p->noise_ahead = false;
     return 0;
 }
 
@@ -1074,6 +1139,7 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
     a.explicit_act = p->explicit_act;
     a.R = p->d_R; a.obs = p->d_obs; a.rew = p->d_rew; a.status = p->d_status;
     a.fobs = p->critic_dim ? p->d_fobs : nullptr;
+    a.next_step = p->d_next_step;
     HIP_OK(p->model->ops->rollout(p->cfg.dtype, a, s));
     if (p->profiling) {
         HIP_OK(hipEventRecord(e1, s));
@@ -1177,45 +1243,71 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
 }
 
 // one whole planning step enqueued on s (no host synchronisation)
-static int enqueue_plan_step(mppi_planner* p, uint64_t seed, int niter, hipStream_t s) {
-    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->P, p->cfg.k_offset, seed, p->d_state, 1, p->fc,
-                                       p->d_eps, s));
+// The noise of the coming step is drawn in the advance launch of the previous one when the handle is small enough
+// for that launch to have idle CUs (the fp64 step next to it sets the kernel's register budget, which would slow a
+// GPU-filling noise pass down).
+static bool plan_draws_ahead(const mppi_planner* p) { return (long)p->cfg.K * p->P <= 65536; }
+
+// niter x (rollouts, update), then the real-env step; the noise of this step must be in place
+static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStream_t s) {
     for (int i = 0; i < niter; i++) {
         int rc = launch_rollout_only(p, s);
         if (!rc) rc = launch_update_fused(p, s);
         if (rc) return rc;
     }
-    HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
-                                  p->d_log, MPPI_LOG_CAP, p->d_log_count, s));
+    if (plan_draws_ahead(p))
+        HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
+                                            p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->cfg.K,
+                                            p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps, s));
+    else
+        HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act,
+                                      p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, s));
+    return 0;
+}
+static int enqueue_plan_noise(mppi_planner* p, uint64_t seed, hipStream_t s) {
+    HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->P, p->cfg.k_offset, seed, p->d_state, 1, p->fc,
+                                       p->d_eps, s));
     return 0;
 }
 
 int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream) {
     if (!p || niter < 1 || nsteps < 0) return fail(-1, "bad argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_plan");
+    if (nsteps == 0) return 0;
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     p->explicit_act = 0;
+    const bool ahead = plan_draws_ahead(p);
+    // with noise drawn ahead only the first step of a run needs a launch of its own
+    const bool have_noise = ahead && p->noise_ahead && p->noise_ahead_seed == seed;
     static const bool use_graph = [] { const char* e = getenv("MPPI_GRAPH"); return !(e && e[0] == '0'); }();
     if (!use_graph || p->profiling) {
-        for (int i = 0; i < nsteps; i++) { int rc = enqueue_plan_step(p, seed, niter, s); if (rc) return rc; }
-        return 0;
+        for (int i = 0; i < nsteps; i++) {
+            int rc = (ahead && (i > 0 || have_noise)) ? 0 : enqueue_plan_noise(p, seed, s);
+            if (!rc) rc = enqueue_plan_body(p, seed, niter, s);
+            if (rc) return rc;
+        }
+    } else {
+        if (!p->step_graph || !p->graph_valid || p->step_graph_niter != niter || p->step_graph_seed != seed) {
+            if (p->step_graph) { HIP_OK(hipGraphExecDestroy(p->step_graph)); p->step_graph = nullptr; }
+            hipGraph_t g;
+            HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+            int rc = ahead ? 0 : enqueue_plan_noise(p, seed, p->stream);
+            if (!rc) rc = enqueue_plan_body(p, seed, niter, p->stream);
+            const hipError_t e = hipStreamEndCapture(p->stream, &g);
+            if (rc) return rc;
+            HIP_OK(e);
+            HIP_OK(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
+            HIP_OK(hipGraphDestroy(g));
+            p->step_graph_niter = niter;
+            p->step_graph_seed = seed;
+            if (!p->graph_valid) { const int rc2 = build_graph(p); if (rc2) return rc2; }    // shares the validity flag
+        }
+        if (ahead && !have_noise) { const int rc = enqueue_plan_noise(p, seed, s); if (rc) return rc; }
+        for (int i = 0; i < nsteps; i++) HIP_OK(hipGraphLaunch(p->step_graph, s));
     }
-    if (!p->step_graph || !p->graph_valid || p->step_graph_niter != niter || p->step_graph_seed != seed) {
-        if (p->step_graph) { HIP_OK(hipGraphExecDestroy(p->step_graph)); p->step_graph = nullptr; }
-        hipGraph_t g;
-        HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_plan_step(p, seed, niter, p->stream);
-        const hipError_t e = hipStreamEndCapture(p->stream, &g);
-        if (rc) return rc;
-        HIP_OK(e);
-        HIP_OK(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
-        HIP_OK(hipGraphDestroy(g));
-        p->step_graph_niter = niter;
-        p->step_graph_seed = seed;
-        if (!p->graph_valid) { const int rc2 = build_graph(p); if (rc2) return rc2; }    // shares the validity flag
-    }
-    for (int i = 0; i < nsteps; i++) HIP_OK(hipGraphLaunch(p->step_graph, s));
+    p->noise_ahead = ahead;
+    p->noise_ahead_seed = seed;
     return 0;
 }
 

@@ -159,6 +159,10 @@ class DevicePlanner:
         """Device-resident advance_time: real-env fp64 step with act_sequence[0], log, shift."""
         L.check(L.lib().mppi_advance(self._h, stream))
 
+    def advance_noise(self, seed, stream=None):
+        """advance() and, in the same launch, generate_noise_step(seed) for the next planning step."""
+        L.check(L.lib().mppi_advance_noise(self._h, int(seed) & (2 ** 64 - 1), stream))
+
     def plan(self, seed, niter=1, nsteps=1, stream=None):
         """nsteps whole planning steps (noise, niter iterations, real-env step, shift) as graph replays."""
         L.check(L.lib().mppi_plan(self._h, int(seed) & (2 ** 64 - 1), int(niter), int(nsteps), stream))

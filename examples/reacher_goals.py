@@ -17,6 +17,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trajopt.algos.mppi import MPPI                      # noqa: E402
 from trajopt.envs.utils import get_environment           # noqa: E402
+from trajopt_amd.agent_io import load_agent              # noqa: E402
 
 
 def reached(sol_obs, radius=0.025):
@@ -60,7 +61,9 @@ def main(argv=None):
         with tempfile.NamedTemporaryFile(suffix='.pickle') as f:
             pickle.dump(agent, f)
             f.flush()
-            agent = pickle.load(open(f.name, 'rb'))
+            agent = pickle.load(open(f.name, 'rb'))      # our own file: fine to unpickle
+            stored = load_agent(f.name)                   # the loader for files from elsewhere: reads, never executes
+            assert len(stored.sol_act) == len(agent.sol_act) and np.array_equal(stored.act_sequence, agent.act_sequence)
         ret, hit, sparse = float(np.sum(agent.sol_reward)), reached(agent.sol_obs), replay_sparse(agent)
         print("seed %d: trajectory reward %.2f, reached %d, sparse replay %.0f, %.2f s" % (seed, ret, hit, sparse, dt))
         results.append((ret, hit, sparse, dt))

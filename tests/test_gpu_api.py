@@ -282,3 +282,34 @@ def test_example_script_flow():
     for ret, hit, sparse, dt in results:
         assert ret > -400.0 and sparse > -116 * 100.0
     assert sum(r[1] for r in results) >= 1           # the hand gets within 2.5 cm of at least one of the goals
+
+
+def test_stored_agent_loads_without_unpickling_and_replays(tmp_path):
+    """play_mppi_agent flow (sandbox/examples/play_mppi_agent.py:22-31) on a stored agent read by the
+    non-executing loader: logged states and actions step to the logged next states, and the run continues."""
+    import pickle
+    from trajopt_amd.agent_io import load_agent
+    from trajopt_amd.algos.mppi import MPPI
+    from trajopt_amd.envs.utils import get_environment
+    e = get_environment('reacher_7dof', reward_type='dense', reference=None)
+    e.reset_model(seed=3, goal=None)
+    agent = MPPI(e, H=8, paths_per_cpu=32, num_cpu=1, kappa=25.0, gamma=1.0, mean=np.zeros(7),
+                 filter_coefs=[np.ones(7), 0.25, 0.8, 0.0], default_act='mean', seed=5)
+    for _ in range(14):
+        agent.train_step(niter=2)
+    path = tmp_path / "agent.pickle"
+    with open(path, "wb") as f:
+        pickle.dump(agent, f)
+    stored = load_agent(str(path))
+    assert stored.H == 8 and stored.kappa == 25.0 and len(stored.sol_state) == 15 and len(stored.sol_act) == 14
+    assert np.array_equal(stored.act_sequence, agent.act_sequence)
+    env = get_environment('reacher_7dof', reward_type='dense', reference=None)
+    env.reset_model(goal=(0, 0, 0), alpha=0.0)
+    for k in range(10, 14):                  # the first ten logged actions are zeros by the reference's rule
+        env.set_env_state(stored.sol_state[k])
+        _, r, _, _ = env.step(stored.sol_act[k])
+        nxt = env.get_env_state()
+        assert np.array_equal(nxt['qp'], stored.sol_state[k + 1]['qp']) and r == stored.sol_reward[k]
+    a2, b2 = stored, agent
+    a2.train_step(niter=2); b2.train_step(niter=2)
+    assert np.array_equal(a2.act_sequence, b2.act_sequence) and np.array_equal(a2.sol_state[-1]['qp'], b2.sol_state[-1]['qp'])

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define MPPI_MAXV 32
-#define MPPI_ABI_VERSION 2
+#define MPPI_ABI_VERSION 3
 #define MPPI_LOG_CAP 4096
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
@@ -34,7 +34,7 @@ enum {
     MPPI_READ_ACT_SEQ = 1,      /* double[H*M]          current act_sequence                            */
     MPPI_READ_ARGMAX = 2,       /* int64[1]             global index of the best sample (first on ties) */
     MPPI_READ_ACTIONS = 3,      /* double[K*H*M]        perturbed actions, sample-major (K,H,M)         */
-    MPPI_READ_NEXT_OBS = 4,     /* double[K*H*(2M+6)]   next_observations (needs cfg.dump)              */
+    MPPI_READ_NEXT_OBS = 4,     /* double[K*H*(nq+M+6)] next_observations (needs cfg.dump); nq = M without balls */
     MPPI_READ_REWARDS = 5,      /* double[K*H]          per-step rewards (needs cfg.dump)               */
     MPPI_READ_STATUS = 6,       /* int32[1]             bit0: non-finite return seen                    */
     MPPI_READ_RMAX = 7,         /* double[1]            best return                                      */
@@ -75,7 +75,9 @@ typedef struct mppi_model_desc {
     double solref_b;
     double solimp[5];
     double gravity[3];
-    int32_t jtype[MPPI_MAXV];   /* 0 hinge, 1 slide along `axis` */
+    int32_t jtype[MPPI_MAXV];   /* 0 hinge, 1 slide along `axis`, 2/3/4 x/y/z component of a ball joint */
+    int32_t nq;                 /* length of qpos: nv + one per ball joint (unit quaternion w, x, y, z)  */
+    int32_t qadr[MPPI_MAXV];    /* qpos index of the joint coordinate; a ball's three links: its quaternion */
 } mppi_model_desc;
 
 /* Planner configuration: the constructor arguments of `MPPI.__init__`

@@ -55,9 +55,11 @@ struct Model {               // mirrors trajopt_amd.model.ModelDesc (flat, row-m
     double solref_b;
     double solimp[5];
     double gravity[3];
-    int jtype[MAXV];           // 0 hinge, 1 slide (translation along `axis`)
+    int jtype[MAXV];           // 0 hinge, 1 slide (translation along `axis`), 2/3/4 x/y/z component of a ball joint
+    int nq;                    // length of qpos: nv + number of ball joints
+    int qadr[MAXV];            // qpos index of the joint coordinate; a ball's three links: its quaternion (w, x, y, z)
 };
-constexpr int JOINT_SLIDE = 1;
+constexpr int JOINT_SLIDE = 1, JOINT_BALL_X = 2, JOINT_BALL_Y = 3, JOINT_BALL_Z = 4;
 
 template <class S> struct V3 { S x, y, z; };
 template <class S> inline V3<S> operator+(V3<S> a, V3<S> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -108,15 +110,34 @@ template <class S> void forward_kinematics(const Model& md, const S* q, Kin<S>& 
         }
         V3<S> off = {S(md.pos[i][0]), S(md.pos[i][1]), S(md.pos[i][2])};
         S ax = S(md.axis[i][0]), ay = S(md.axis[i][1]), az = S(md.axis[i][2]);
+        const int qa = md.qadr[i];
         if (md.jtype[i] == JOINT_SLIDE) {
-            k.p[i] = pp + mul(Rp, off + q[i] * V3<S>{ax, ay, az});
+            k.p[i] = pp + mul(Rp, off + q[qa] * V3<S>{ax, ay, az});
+            k.R[i] = Rp;
+            k.a[i] = mul(Rp, V3<S>{ax, ay, az});
+            continue;
+        }
+        if (md.jtype[i] == JOINT_BALL_X) {
+            // body frame from the unit quaternion; the ball's three links share it, their axes are its columns
+            const S w = q[qa], x = q[qa + 1], y = q[qa + 2], z = q[qa + 3], two = S(2.0), one = S(1.0);
+            M3<S> Rq;
+            Rq.m[0][0] = one - two * (y * y + z * z); Rq.m[0][1] = two * (x * y - w * z); Rq.m[0][2] = two * (x * z + w * y);
+            Rq.m[1][0] = two * (x * y + w * z); Rq.m[1][1] = one - two * (x * x + z * z); Rq.m[1][2] = two * (y * z - w * x);
+            Rq.m[2][0] = two * (x * z - w * y); Rq.m[2][1] = two * (y * z + w * x); Rq.m[2][2] = one - two * (x * x + y * y);
+            k.p[i] = pp + mul(Rp, off);
+            k.R[i] = mul(Rp, Rq);
+            k.a[i] = mul(k.R[i], V3<S>{ax, ay, az});
+            continue;
+        }
+        if (md.jtype[i] == JOINT_BALL_Y || md.jtype[i] == JOINT_BALL_Z) {
+            k.p[i] = pp;
             k.R[i] = Rp;
             k.a[i] = mul(Rp, V3<S>{ax, ay, az});
             continue;
         }
         k.p[i] = pp + mul(Rp, off);
         // Rodrigues rotation about the link-frame axis
-        S s = sin(q[i]), c = cos(q[i]);
+        S s = sin(q[qa]), c = cos(q[qa]);
         S t = S(1.0) - c;
         M3<S> Rj;
         Rj.m[0][0] = c + t * ax * ax;      Rj.m[0][1] = t * ax * ay - s * az; Rj.m[0][2] = t * ax * az + s * ay;
@@ -197,9 +218,14 @@ template <class S> void inertia_and_bias(const Model& md, const Kin<S>& k, const
         Sp6<S> Sq = {qd[i] * Sx[i].w, qd[i] * Sx[i].v};
         V[i].w = Vp.w + Sq.w;
         V[i].v = Vp.v + Sq.v;
-        // d/dt of the joint axis carried by the parent: Vp x Sq
-        A[i].w = Ap.w + cross(Vp.w, Sq.w);
-        A[i].v = Ap.v + cross(Vp.w, Sq.v) + cross(Vp.v, Sq.w);
+        // d/dt of the joint axis, carried by the parent: Vp x Sq.  The three axes of a ball joint are all fixed
+        // in the body and turn with it; summed over the joint that equals carrying each with the velocity of
+        // the link in front of the ball (the joint's own rate crossed with itself vanishes).
+        Sp6<S> Vc = Vp;
+        if (md.jtype[i] == JOINT_BALL_Y) { int b = md.parent[pi]; if (b >= 0) Vc = V[b]; else { Vc.w = Vc.v = {S(0.0), S(0.0), S(0.0)}; } }
+        if (md.jtype[i] == JOINT_BALL_Z) { int b = md.parent[md.parent[pi]]; if (b >= 0) Vc = V[b]; else { Vc.w = Vc.v = {S(0.0), S(0.0), S(0.0)}; } }
+        A[i].w = Ap.w + cross(Vc.w, Sq.w);
+        A[i].v = Ap.v + cross(Vc.w, Sq.v) + cross(Vc.v, Sq.w);
         Sp6<S> IA = apply(I[i], A[i]);
         Sp6<S> IV = apply(I[i], V[i]);
         F[i].w = IA.w + cross(V[i].w, IV.w) + cross(V[i].v, IV.v);
@@ -317,8 +343,8 @@ void substep(const Model& md, const S* q, const S* v, const S* ctrl, S* q_out, S
     };
     for (int j = 0; j < nv; j++) {
         if (!md.limited[j]) continue;
-        S lo = q[j] - S(md.range_lo[j]);
-        S hi = S(md.range_hi[j]) - q[j];
+        S lo = q[md.qadr[j]] - S(md.range_lo[j]);
+        S hi = S(md.range_hi[j]) - q[md.qadr[j]];
         if (lo < S(0.0)) {
             for (int c = 0; c < nv; c++) J[nrow][c] = S(0.0);
             J[nrow][j] = S(1.0);
@@ -396,9 +422,29 @@ void substep(const Model& md, const S* q, const S* v, const S* ctrl, S* q_out, S
     }
     cholesky(B, nv);
     chol_solve(B, nv, qacc);
+    for (int j = 0; j < nv; j++) v_out[j] = v[j] + S(md.h) * qacc[j];
     for (int j = 0; j < nv; j++) {
-        v_out[j] = v[j] + S(md.h) * qacc[j];
-        q_out[j] = q[j] + S(md.h) * v_out[j];
+        const int qa = md.qadr[j];
+        if (md.jtype[j] == JOINT_BALL_X) {
+            // q <- q * exp(h w / 2) with w the new angular velocity in the body frame, then renormalised
+            const S wx = v_out[j], wy = v_out[j + 1], wz = v_out[j + 2];
+            const S n = sqrt(wx * wx + wy * wy + wz * wz);
+            const S half = S(0.5) * S(md.h) * n;
+            S c = cos(half), f;                                  // f = sin(half) / n
+            if (n > S(1e-12)) f = sin(half) / n; else f = S(0.5) * S(md.h);
+            const S dw = c, dx = f * wx, dy = f * wy, dz = f * wz;
+            const S a = q[qa], b = q[qa + 1], cc = q[qa + 2], d = q[qa + 3];
+            S r0 = a * dw - b * dx - cc * dy - d * dz;
+            S r1 = a * dx + b * dw + cc * dz - d * dy;
+            S r2 = a * dy - b * dz + cc * dw + d * dx;
+            S r3 = a * dz + b * dy - cc * dx + d * dw;
+            const S inv = S(1.0) / sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+            q_out[qa] = r0 * inv; q_out[qa + 1] = r1 * inv; q_out[qa + 2] = r2 * inv; q_out[qa + 3] = r3 * inv;
+        } else if (md.jtype[j] == JOINT_BALL_Y || md.jtype[j] == JOINT_BALL_Z) {
+            continue;
+        } else {
+            q_out[qa] = q[qa] + S(md.h) * v_out[j];
+        }
     }
     delete k;
     delete d;

@@ -72,15 +72,15 @@ void oracle_mass_matrix(const Model* md, const double* q, const double* qd, doub
 void oracle_env_step(const Model* md, const double* q, const double* v, const double* target, const double* act,
                      int env_timestep, int reward_type, const double* reference, int ref_len, double alpha,
                      double* q_out, double* v_out, double* obs, double* reward_out, int* info3) {
-    const int nv = md->nv;
+    const int nv = md->nv, nq = md->nq;
     double qa[MAXV], va[MAXV], qb[MAXV], vb[MAXV];
-    std::memcpy(qa, q, nv * sizeof(double));
+    std::memcpy(qa, q, nq * sizeof(double));
     std::memcpy(va, v, nv * sizeof(double));
     V3<double> hand = {0, 0, 0};
     StepInfo inf, acc = {0, 0, 0};
     for (int s = 0; s < md->frame_skip; s++) {
         substep<double>(*md, qa, va, act, qb, vb, &hand, &inf);
-        std::memcpy(qa, qb, nv * sizeof(double));
+        std::memcpy(qa, qb, nq * sizeof(double));
         std::memcpy(va, vb, nv * sizeof(double));
         acc.nrows += inf.nrows; acc.nactive += inf.nactive; if (inf.sweeps > acc.sweeps) acc.sweeps = inf.sweeps;
     }
@@ -92,11 +92,12 @@ void oracle_env_step(const Model* md, const double* q, const double* v, const do
         ref_row = reference + 3 * idx;
     }
     if (reward_out) *reward_out = reward(reward_type, h3, target, va, nv, ref_row, alpha);
-    std::memcpy(q_out, qa, nv * sizeof(double));
+    std::memcpy(q_out, qa, nq * sizeof(double));
     std::memcpy(v_out, va, nv * sizeof(double));
     if (obs) {
-        for (int j = 0; j < nv; j++) { obs[j] = qa[j]; obs[nv + j] = va[j]; }
-        for (int c = 0; c < 3; c++) { obs[2 * nv + c] = h3[c]; obs[2 * nv + 3 + c] = target[c]; }
+        for (int j = 0; j < nq; j++) obs[j] = qa[j];
+        for (int j = 0; j < nv; j++) obs[nq + j] = va[j];
+        for (int c = 0; c < 3; c++) { obs[nq + nv + c] = h3[c]; obs[nq + nv + 3 + c] = target[c]; }
     }
     if (info3) { info3[0] = acc.nrows; info3[1] = acc.nactive; info3[2] = acc.sweeps; }
 }
@@ -108,8 +109,8 @@ void oracle_rollout(const Model* md, const double* q0, const double* v0, const d
                     const double* act, int K, int H, int reward_type, const double* reference, int ref_len,
                     double alpha, double gamma, double* returns, double* next_obs, double* rewards,
                     int nthreads) {
-    const int nv = md->nv;
-    const int od = 2 * nv + 6;
+    const int nv = md->nv, nq = md->nq;
+    const int od = nq + nv + 6;
     if (nthreads < 1) nthreads = 1;
     std::atomic<int> next(0);
     auto work = [&]() {
@@ -118,14 +119,14 @@ void oracle_rollout(const Model* md, const double* q0, const double* v0, const d
             int k = next.fetch_add(1);
             if (k >= K) break;
             double q[MAXV], v[MAXV], q2[MAXV], v2[MAXV];
-            std::memcpy(q, q0, nv * sizeof(double));
+            std::memcpy(q, q0, nq * sizeof(double));
             std::memcpy(v, v0, nv * sizeof(double));
             double R = 0.0;
             for (int t = 0; t < H; t++) {
                 double r;
                 oracle_env_step(md, q, v, target, act + ((size_t)k * H + t) * nv, timestep0 + t, reward_type,
                                 reference, ref_len, alpha, q2, v2, obs.data(), &r, nullptr);
-                std::memcpy(q, q2, nv * sizeof(double));
+                std::memcpy(q, q2, nq * sizeof(double));
                 std::memcpy(v, v2, nv * sizeof(double));
                 R += std::pow(gamma, (double)t) * r;
                 if (rewards) rewards[(size_t)k * H + t] = r;
@@ -146,7 +147,8 @@ void oracle_rollout(const Model* md, const double* q0, const double* v0, const d
 // algorithmic operation count of one substep at the given state
 void oracle_count_ops(const Model* md, const double* q, const double* v, const double* ctrl, long* counts6) {
     Counted cq[MAXV], cv[MAXV], cc[MAXV], qo[MAXV], vo[MAXV];
-    for (int j = 0; j < md->nv; j++) { cq[j] = Counted(q[j]); cv[j] = Counted(v[j]); cc[j] = Counted(ctrl[j]); }
+    for (int j = 0; j < md->nq; j++) cq[j] = Counted(q[j]);
+    for (int j = 0; j < md->nv; j++) { cv[j] = Counted(v[j]); cc[j] = Counted(ctrl[j]); }
     g_add = g_mul = g_div = g_sqrt = g_trig = g_cmp = 0;
     V3<Counted> hand;
     StepInfo inf;

@@ -22,7 +22,7 @@ class CModel(C.Structure):
         ("dof_invweight", _d * MAXV), ("contact_pos", _d * 3), ("contact_radius", _d),
         ("contact_plane_z", _d), ("contact_margin", _d), ("contact_invweight", _d),
         ("hand_pos", _d * 3), ("solref_k", _d), ("solref_b", _d), ("solimp", _d * 5),
-        ("gravity", _d * 3), ("jtype", _i * MAXV),
+        ("gravity", _d * 3), ("jtype", _i * MAXV), ("nq", _i), ("qadr", _i * MAXV),
     ]
 
 
@@ -44,9 +44,11 @@ def lib():
 def to_cmodel(md) -> CModel:
     m = CModel()
     m.nv, m.frame_skip, m.h = md.nv, md.frame_skip, md.h
+    m.nq = int(md.nq)
     m.contact_link, m.hand_link = md.contact_link, md.hand_link
     for i in range(md.nv):
         m.parent[i] = int(md.parent[i]); m.limited[i] = int(md.limited[i]); m.jtype[i] = int(md.jtype[i])
+        m.qadr[i] = int(md.qadr[i])
         for c in range(3):
             m.pos[i][c] = md.pos[i][c]; m.axis[i][c] = md.axis[i][c]; m.com[i][c] = md.com[i][c]
         for c in range(6):
@@ -79,11 +81,12 @@ class OracleSim:
         self.md = md
         self.cm = to_cmodel(md)
         self.nv = md.nv
+        self.nq = md.nq
         self.L = lib()
 
     def substep(self, q, v, ctrl):
         q, v, ctrl = _f64(q), _f64(v), _f64(ctrl)
-        q2, v2, hand = np.zeros(self.nv), np.zeros(self.nv), np.zeros(3)
+        q2, v2, hand = np.zeros(self.nq), np.zeros(self.nv), np.zeros(3)
         info = np.zeros(3, np.int32)
         self.L.oracle_substep(C.byref(self.cm), _p(q), _p(v), _p(ctrl), _p(q2), _p(v2), _p(hand), _p(info))
         return q2, v2, hand, info
@@ -104,7 +107,7 @@ class OracleSim:
     def env_step(self, q, v, target, act, env_timestep=0, reward_type="dense", reference=None, alpha=1.0):
         q, v, target, act = _f64(q), _f64(v), _f64(target), _f64(act)
         ref = None if reference is None else _f64(reference)
-        q2, v2, obs = np.zeros(self.nv), np.zeros(self.nv), np.zeros(2 * self.nv + 6)
+        q2, v2, obs = np.zeros(self.nq), np.zeros(self.nv), np.zeros(self.nq + self.nv + 6)
         r = C.c_double(0.0)
         info = np.zeros(3, np.int32)
         self.L.oracle_env_step(C.byref(self.cm), _p(q), _p(v), _p(target), _p(act), _i(int(env_timestep)),
@@ -120,7 +123,7 @@ class OracleSim:
         K, H, _ = act.shape
         ref = None if reference is None else _f64(reference)
         R = np.zeros(K)
-        nobs = np.zeros((K, H, 2 * self.nv + 6)) if dump else None
+        nobs = np.zeros((K, H, self.nq + self.nv + 6)) if dump else None
         rew = np.zeros((K, H)) if dump else None
         self.L.oracle_rollout(C.byref(self.cm), _p(q0), _p(v0), _p(target), _i(int(timestep0)), _p(act),
                               _i(K), _i(H), _i(REWARD_TYPES[reward_type]), None if ref is None else _p(ref),

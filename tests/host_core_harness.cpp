@@ -9,9 +9,10 @@ template <class T, class MD>
 static void run(const double* q0, const double* v0, const double* target, const double* act, int H, int reward_type,
                 const double* ref, int t0, double alpha, double gamma, double* q_out, double* v_out, double* hand_out,
                 double* rewards, double* ret, int* sweeps) {
-    constexpr int NV = MD::NV;
-    T q[NV], v[NV];
-    for (int j = 0; j < NV; j++) { q[j] = T(q0[j]); v[j] = T(v0[j]); }
+    constexpr int NV = MD::NV, NQ = MD::NQ;
+    T q[NQ], v[NV];
+    for (int j = 0; j < NQ; j++) q[j] = T(q0[j]);
+    for (int j = 0; j < NV; j++) v[j] = T(v0[j]);
     RewardParams<T> rp;
     rp.type = reward_type; rp.alpha = T(alpha);
     for (int c = 0; c < 3; c++) rp.target[c] = T(target[c]);
@@ -29,7 +30,8 @@ static void run(const double* q0, const double* v0, const double* target, const 
         if (rewards) rewards[t] = double(r);
         R += g * r; g *= T(gamma);
     }
-    for (int j = 0; j < NV; j++) { q_out[j] = double(q[j]); v_out[j] = double(v[j]); }
+    for (int j = 0; j < NQ; j++) q_out[j] = double(q[j]);
+    for (int j = 0; j < NV; j++) v_out[j] = double(v[j]);
     for (int c = 0; c < 3; c++) hand_out[c] = double(hand.v[c]);
     *ret = double(R); *sweeps = ms;
 }
@@ -41,6 +43,7 @@ extern "C" void core_rollout(int f64, int model, const double* q0, const double*
 #define GO(T, MD) run<T, MD>(q0, v0, target, act, H, reward_type, ref, t0, alpha, gamma, q_out, v_out, hand_out, rewards, ret, sweeps)
     if (model == 0) { if (f64) GO(double, Reacher7Dof); else GO(float, Reacher7Dof); }
     else if (model == 1) { if (f64) GO(double, Reacher7DofFree); else GO(float, Reacher7DofFree); }
-    else                 { if (f64) GO(double, Tree18Dof); else GO(float, Tree18Dof); }
+    else if (model == 2) { if (f64) GO(double, Tree18Dof); else GO(float, Tree18Dof); }
+    else                 { if (f64) GO(double, Tree18DofQuat); else GO(float, Tree18DofQuat); }
 }
 

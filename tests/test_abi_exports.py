@@ -22,14 +22,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert L.mppi_version() == 2
+    assert L.mppi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
     from trajopt_amd import _lib
     # sizes implied by the header's field lists (int32 / double, natural alignment)
     nd = 32
-    model = 64 + 4 * 2 + 4 * nd * 2 + 4 * 2 + 8 + 8 * (3 * nd * 3 + 6 * nd + 9 * nd) + 8 * (3 + 4 + 3 + 2 + 5) + 8 * 3 + 4 * nd
+    model = 64 + 4 * 2 + 4 * nd * 2 + 4 * 2 + 8 + 8 * (3 * nd * 3 + 6 * nd + 9 * nd) + 8 * (3 + 4 + 3 + 2 + 5) + 8 * 3 + 4 * nd + 4 + 4 * nd + 4
     assert ctypes.sizeof(_lib.ModelDescC) == model
     assert ctypes.sizeof(_lib.PlannerCfgC) == 4 * 10 + 8 * 2 + 8 * (nd + 3 + nd)
 

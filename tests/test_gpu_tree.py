@@ -107,3 +107,75 @@ def test_tree_planning_iteration(tree):
     log = p.read_log()
     assert log["total"] == 1 and np.isfinite(log["qpos"]).all()
     p.close()
+
+
+# ---- the same tree on a free joint with a quaternion (tree_18dof_quat: nq = 19, nv = 18) ------------------
+NQ = 19
+
+
+@pytest.fixture(scope="module")
+def treeq():
+    from trajopt_amd.device import DeviceModel
+    return DeviceModel.get("tree_18dof_quat")
+
+
+@pytest.fixture(scope="module")
+def treeq_oracle():
+    from oracle.sim import OracleSim
+    from trajopt_amd.model import get_model
+    return OracleSim(get_model("tree_18dof_quat"))
+
+
+def _start_quat(seed=3):
+    rs = np.random.RandomState(seed)
+    quat = rs.randn(4)
+    q0 = np.r_[0.0, 0.0, 0.0, quat / np.linalg.norm(quat), rs.randn(12) * 0.3]
+    return q0, rs.randn(NV) * 0.5, np.array([0.4, 0.1, 0.8])
+
+
+def test_quat_tree_fp64_against_oracle(treeq, treeq_oracle):
+    K, H = 128, 128
+    q0, v0, tgt = _start_quat()
+    p = _run(treeq, "f64", K, H, q0, v0, tgt, 5)
+    act, nobs, rew, R = p.actions(), p.next_observations(), p.rewards(), p.returns()
+    assert p.status() == 0 and nobs.shape == (K, H, NQ + NV + 6)
+    R_o, nobs_o, rew_o = treeq_oracle.rollout(q0, v0, tgt, 0, act, gamma=0.99, dump=True, nthreads=4)
+    assert np.abs(nobs - nobs_o).max() < 1e-8
+    assert np.abs(rew - rew_o).max() < 1e-8 and np.abs(R - R_o).max() < 1e-7
+    assert np.abs(np.linalg.norm(nobs[..., 3:7], axis=-1) - 1.0).max() < 1e-12
+    # it tumbles: the trunk's orientation moves well away from where it started
+    assert np.abs(nobs[:, -1, 3:7] - q0[3:7]).max() > 0.2
+    p.close()
+
+
+def test_quat_tree_single_step_and_site(treeq, treeq_oracle):
+    rs = np.random.RandomState(9)
+    for s in range(4):
+        q, v, tgt = _start_quat(20 + s)
+        a = rs.randn(NV) * 2
+        q2, v2, obs, r = treeq.env_step(q, v, tgt, a, 0)
+        qo, vo, obs_o, ro, _ = treeq_oracle.env_step(q, v, tgt, a)
+        assert np.abs(q2 - qo).max() < 1e-12 and np.abs(v2 - vo).max() < 1e-11
+        assert np.abs(obs - obs_o).max() < 1e-11 and abs(r - ro) < 1e-11
+        assert np.allclose(treeq.forward_hand(q), treeq_oracle.fk_hand(q), atol=1e-13)
+
+
+def test_quat_tree_fp32_error_growth_and_planning(treeq):
+    K, H = 2048, 128
+    q0, v0, tgt = _start_quat()
+    p64 = _run(treeq, "f64", K, H, q0, v0, tgt, 2024)
+    p32 = _run(treeq, "f32", K, H, q0, v0, tgt, 2024)
+    o64, o32 = p64.next_observations()[..., :NQ + NV], p32.next_observations()[..., :NQ + NV]
+    assert p32.status() == 0
+    rel = np.abs(o32 - o64) / (1.0 + np.abs(o64))
+    med = [float(np.median(rel[:, t - 1].max(axis=1))) for t in (32, 64, 128)]
+    p99 = [float(np.percentile(rel[:, t - 1].max(axis=1), 99)) for t in (32, 64, 128)]
+    print("fp32 quaternion tree error median", med, "p99", p99)
+    assert med[0] < 1e-4 and med[2] < 1e-3 and p99[2] < 2e-2
+    assert np.abs(np.linalg.norm(o32[..., 3:7], axis=-1) - 1.0).max() < 1e-6
+    # a whole planning step: update, real-env step in fp64, log with the 19-entry qpos
+    p32.iterate(1)
+    p32.advance()
+    log = p32.read_log()
+    assert log["total"] == 1 and log["qpos"].shape == (1, NQ) and abs(np.linalg.norm(log["qpos"][0, 3:7]) - 1.0) < 1e-14
+    p64.close(); p32.close()

@@ -25,7 +25,7 @@ def core():
         q0, v0, tgt, act = (np.ascontiguousarray(x, dtype=np.float64) for x in (q0, v0, tgt, act))
         H = act.shape[0]
         nv = act.shape[1]
-        q, v, hand, rew = np.zeros(nv), np.zeros(nv), np.zeros(3), np.zeros(H)
+        q, v, hand, rew = np.zeros(len(q0)), np.zeros(nv), np.zeros(3), np.zeros(H)
         R, sw = C.c_double(), C.c_int()
         refp = None if ref is None else p(np.ascontiguousarray(ref, dtype=np.float64))
         L.core_rollout(int(f64), model, p(q0), p(v0), p(tgt), p(act), H, rt, refp, t0, C.c_double(alpha),
@@ -103,3 +103,28 @@ def test_tree_model_slides_and_gravity(core):
     q, v, _, _, R32, _ = core(0, q0, v0, tgt, act, gamma=0.99, model=2)
     assert (np.abs(np.r_[q, v] - nobs_o[0, -1, :36]) / (1 + np.abs(nobs_o[0, -1, :36]))).max() < 2e-3
 
+
+
+def test_free_joint_with_quaternion(core):
+    """Ball joint in the link-local kernel arithmetic (rotation matrix from the quaternion, body-fixed axes,
+    quaternion integration) against the world-frame oracle, on a tumbling, falling tree."""
+    from oracle.sim import OracleSim
+    from trajopt_amd.model import get_model
+    md = get_model("tree_18dof_quat")
+    sim = OracleSim(md)
+    rs = np.random.RandomState(12)
+    H = 64
+    q0 = md.qpos0()
+    q0[:3] = rs.randn(3) * 0.2
+    quat = rs.randn(4)
+    q0[3:7] = quat / np.linalg.norm(quat)
+    q0[7:] = rs.randn(12) * 0.4
+    v0, tgt = rs.randn(18) * 0.8, np.array([0.3, 0.1, 1.0])
+    act = rs.randn(H, 18)
+    R_o, nobs_o, rew_o = sim.rollout(q0, v0, tgt, 0, act[None], gamma=0.99, dump=True)
+    q, v, hand, rew, R, sw = core(1, q0, v0, tgt, act, gamma=0.99, model=3)
+    assert np.abs(q - nobs_o[0, -1, :19]).max() < 1e-9 and np.abs(v - nobs_o[0, -1, 19:37]).max() < 1e-9
+    assert np.abs(rew - rew_o[0]).max() < 1e-9 and abs(R - R_o[0]) < 1e-8
+    assert np.abs(hand - nobs_o[0, -1, 37:40]).max() < 1e-10 and abs(np.linalg.norm(q[3:7]) - 1) < 1e-14
+    q, v, _, _, R32, _ = core(0, q0, v0, tgt, act, gamma=0.99, model=3)
+    assert (np.abs(np.r_[q, v] - nobs_o[0, -1, :37]) / (1 + np.abs(nobs_o[0, -1, :37]))).max() < 2e-3

@@ -15,36 +15,41 @@ constexpr int NV = MD::NV;
 __global__ void __launch_bounds__(64) c_io_only(const float* in, float* out) {
     static_for<3 * NV>([&](auto I) { OUT(I) = IN(I); });
 }
-__global__ void __launch_bounds__(64) c_trig(const float* in, float* out) {
-    float q[NV], cs[NV], sn[NV];
+__global__ void __launch_bounds__(64) c_frames(const float* in, float* out) {
+    float q[NV];
+    typename S::Frames fr;
     static_for<NV>([&](auto I) { q[I] = IN(I); });
-    S::trig(q, cs, sn);
-    static_for<NV>([&](auto I) { OUT(I) = cs[I]; OUT(NV + I) = sn[I]; });
+    S::frames(q, fr);
+    static_for<NV>([&](auto I) { OUT(I) = fr.cs(I); OUT(NV + I) = fr.sn(I); });
 }
 __global__ void __launch_bounds__(64) c_smooth_force(const float* in, float* out) {
-    float q[NV], cs[NV], sn[NV], qd[NV], u[NV], fs[NV];
-    static_for<NV>([&](auto I) { q[I] = 0; cs[I] = IN(I); sn[I] = IN(NV + I); qd[I] = IN(2 * NV + I); u[I] = IN(3 * NV + I); });
-    S::smooth_force(q, cs, sn, qd, u, fs);
+    float q[NV], qd[NV], u[NV], fs[NV];
+    typename S::Frames fr;
+    static_for<NV>([&](auto I) { q[I] = 0; fr.cs(I) = IN(I); fr.sn(I) = IN(NV + I); qd[I] = IN(2 * NV + I); u[I] = IN(3 * NV + I); });
+    S::smooth_force(q, fr, qd, u, fs);
     static_for<NV>([&](auto I) { OUT(I) = fs[I]; });
 }
 __global__ void __launch_bounds__(64) c_mass_matrix(const float* in, float* out) {
-    float q[NV], cs[NV], sn[NV], M[NV][NV];
-    static_for<NV>([&](auto I) { q[I] = 0; cs[I] = IN(I); sn[I] = IN(NV + I); });
-    S::mass_matrix(q, cs, sn, M);
+    float q[NV], M[NV][NV];
+    typename S::Frames fr;
+    static_for<NV>([&](auto I) { q[I] = 0; fr.cs(I) = IN(I); fr.sn(I) = IN(NV + I); });
+    S::mass_matrix(q, fr, M);
     static_for<NV>([&](auto I) { static_for<I + 1>([&](auto J) { OUT(I * NV + J) = M[I][J]; }); });
 }
 __global__ void __launch_bounds__(64) c_build_rows(const float* in, float* out) {
-    float q[NV], cs[NV], sn[NV], qd[NV];
-    static_for<NV>([&](auto I) { q[I] = IN(3 * NV + I); cs[I] = IN(I); sn[I] = IN(NV + I); qd[I] = IN(2 * NV + I); });
+    float q[NV], qd[NV];
+    typename S::Frames fr;
+    static_for<NV>([&](auto I) { q[I] = IN(3 * NV + I); fr.cs(I) = IN(I); fr.sn(I) = IN(NV + I); qd[I] = IN(2 * NV + I); });
     typename S::Rows r;
-    S::build_rows(q, cs, sn, qd, r);
+    S::build_rows(q, fr, qd, r);
     static_for<NV>([&](auto I) { OUT(I) = r.Dl[I]; OUT(NV + I) = r.arl[I]; OUT(2 * NV + I) = r.sg[I]; OUT(3 * NV + I) = r.Jc[I]; });
     OUT(4 * NV) = r.Dc + r.arc + (r.any ? 1.f : 0.f);
 }
 __global__ void __launch_bounds__(64) c_hand_site(const float* in, float* out) {
-    float q[NV], cs[NV], sn[NV];
-    static_for<NV>([&](auto I) { q[I] = 0; cs[I] = IN(I); sn[I] = IN(NV + I); });
-    const Vec3<float> h = S::hand_site(q, cs, sn);
+    float q[NV];
+    typename S::Frames fr;
+    static_for<NV>([&](auto I) { q[I] = 0; fr.cs(I) = IN(I); fr.sn(I) = IN(NV + I); });
+    const Vec3<float> h = S::hand_site(q, fr);
     OUT(0) = h.v[0]; OUT(1) = h.v[1]; OUT(2) = h.v[2];
 }
 __global__ void __launch_bounds__(64) c_chol_solve(const float* in, float* out) {

@@ -151,6 +151,49 @@ template <class T, class E> MPPI_HD Vec3<E> sym_mul(const T (&I)[6], const Vec3<
 
 template <class T, class MD> struct Step {
     static constexpr int NV = MD::NV;
+    static constexpr int NQ = MD::NQ;            // qpos entries: NV + one per ball joint (unit quaternion)
+    static constexpr bool is_ball(int i) { return MD::jtype[i] >= 2; }
+    static constexpr bool any_ball() {
+        for (int i = 0; i < NV; i++) if (MD::jtype[i] >= 2) return true;
+        return false;
+    }
+
+    // Orientation of every link frame in its parent's frame: an angle about a coordinate axis for a hinge,
+    // a rotation matrix (from the unit quaternion) for the first link of a ball joint, identity otherwise.
+    template <bool BALLS, class Dummy = void> struct FramesRb { T rb[NV][9]; };     // row-major
+    template <class Dummy> struct FramesRb<false, Dummy> {};
+    struct Frames : FramesRb<any_ball()> {
+        alignas(8) T c_s[NV][2];     // cosine and sine of every hinge angle, side by side
+        MPPI_HD T& cs(int i) { return c_s[i][0]; }
+        MPPI_HD T& sn(int i) { return c_s[i][1]; }
+        MPPI_HD const T& cs(int i) const { return c_s[i][0]; }
+        MPPI_HD const T& sn(int i) const { return c_s[i][1]; }
+    };
+    // the rotation matrix of link I (a template so that ball-free models never name the member)
+    template <int I, class Fr> static MPPI_HD auto& rb_of(Fr& fr) { return fr.rb[I]; }
+    // parent coordinates -> link-I coordinates and back, for single vectors and pairs alike
+    template <int I, class E> static MPPI_HD Vec3<E> down(const Frames& fr, const Vec3<E>& x) {
+        if constexpr (MD::jtype[I] == 0) {
+            return to_child<MD::axis_id[I]>(fr.cs(I), fr.sn(I), x);
+        } else if constexpr (MD::jtype[I] == 2) {
+            const T (&R)[9] = rb_of<I>(fr);
+            return {{R[0] * x.v[0] + R[3] * x.v[1] + R[6] * x.v[2], R[1] * x.v[0] + R[4] * x.v[1] + R[7] * x.v[2],
+                     R[2] * x.v[0] + R[5] * x.v[1] + R[8] * x.v[2]}};
+        } else {
+            return x;
+        }
+    }
+    template <int I, class E> static MPPI_HD Vec3<E> up(const Frames& fr, const Vec3<E>& x) {
+        if constexpr (MD::jtype[I] == 0) {
+            return to_parent<MD::axis_id[I]>(fr.cs(I), fr.sn(I), x);
+        } else if constexpr (MD::jtype[I] == 2) {
+            const T (&R)[9] = rb_of<I>(fr);
+            return {{R[0] * x.v[0] + R[1] * x.v[1] + R[2] * x.v[2], R[3] * x.v[0] + R[4] * x.v[1] + R[5] * x.v[2],
+                     R[6] * x.v[0] + R[7] * x.v[1] + R[8] * x.v[2]}};
+        } else {
+            return x;
+        }
+    }
 
     struct Out {
         Vec3<T> hand;        // end-effector site in world coordinates at the input q
@@ -158,9 +201,9 @@ template <class T, class MD> struct Step {
 
     template <int I> static MPPI_HD Vec3<T> pos_() { return {{T(MD::pos[I][0]), T(MD::pos[I][1]), T(MD::pos[I][2])}}; }
     // origin of link I in its parent's frame: constant for a hinge, displaced along the axis by q for a slide
-    template <int I> static MPPI_HD Vec3<T> off_(const T (&q)[NV]) {
+    template <int I> static MPPI_HD Vec3<T> off_(const T (&q)[NQ]) {
         Vec3<T> r = pos_<I>();
-        if constexpr (MD::jtype[I] == 1) r.v[MD::axis_id[I]] += T(MD::axis_sign[I]) * q[I];
+        if constexpr (MD::jtype[I] == 1) r.v[MD::axis_id[I]] += T(MD::axis_sign[I]) * q[MD::qadr[I]];
         return r;
     }
     template <int I> static MPPI_HD Vec3<T> mc_() { return {{T(MD::mc[I][0]), T(MD::mc[I][1]), T(MD::mc[I][2])}}; }
@@ -177,11 +220,11 @@ template <class T, class MD> struct Step {
     // coordinates of a point fixed in link I, expressed in every ancestor frame on the way to the
     // world: x[i] = point in link-i coordinates, returns world coordinates
     template <int I>
-    static MPPI_HD Vec3<T> point_to_world(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const Vec3<T>& x,
+    static MPPI_HD Vec3<T> point_to_world(const T (&q)[NQ], const Frames& fr, const Vec3<T>& x,
                                           Vec3<T> (&xs)[NV]) {
         xs[I] = x;
-        const Vec3<T> xp = add(off_<I>(q), to_parent<MD::axis_id[I]>(cs[I], sn[I], x));
-        if constexpr (MD::parent[I] >= 0) return point_to_world<MD::parent[I]>(q, cs, sn, xp, xs);
+        const Vec3<T> xp = add(off_<I>(q), up<I>(fr, x));
+        if constexpr (MD::parent[I] >= 0) return point_to_world<MD::parent[I]>(q, fr, xp, xs);
         else return xp;
     }
 
@@ -199,35 +242,43 @@ template <class T, class MD> struct Step {
         MPPI_HD void reset() { static_for<NV + 1>([&](auto Ic) { row[Ic] = T(1); }); }
     };
 
-    static MPPI_HD void trig(const T (&q)[NV], T (&cs)[NV], T (&sn)[NV]) {
+    static MPPI_HD void frames(const T (&q)[NQ], Frames& fr) {
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
-            if constexpr (MD::jtype[i] == 1) {
-                cs[i] = T(1); sn[i] = T(0);          // a slide does not turn its frame
-            } else {
+            constexpr int a = MD::qadr[i];
+            if constexpr (MD::jtype[i] == 0) {
                 T s, c;
-                sincos_t(q[i], s, c);
-                cs[i] = c;
-                sn[i] = (MD::axis_sign[i] > 0) ? s : -s;
+                sincos_t(q[a], s, c);
+                fr.cs(i) = c;
+                fr.sn(i) = (MD::axis_sign[i] > 0) ? s : -s;
+            } else {
+                fr.cs(i) = T(1); fr.sn(i) = T(0);    // slides and the later links of a ball joint do not turn their frame
+                if constexpr (MD::jtype[i] == 2) {
+                    const T w = q[a], x = q[a + 1], y = q[a + 2], z = q[a + 3];
+                    T (&R)[9] = rb_of<decltype(Ic)::value>(fr);
+                    R[0] = T(1) - T(2) * (y * y + z * z); R[1] = T(2) * (x * y - w * z); R[2] = T(2) * (x * z + w * y);
+                    R[3] = T(2) * (x * y + w * z); R[4] = T(1) - T(2) * (x * x + z * z); R[5] = T(2) * (y * z - w * x);
+                    R[6] = T(2) * (x * z - w * y); R[7] = T(2) * (y * z + w * x); R[8] = T(1) - T(2) * (x * x + y * y);
+                }
             }
         });
     }
 
     // end-effector site in world coordinates
-    static MPPI_HD Vec3<T> hand_site(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV]) {
+    static MPPI_HD Vec3<T> hand_site(const T (&q)[NQ], const Frames& fr) {
         if constexpr (MD::hand_link >= 0) {
             Vec3<T> tmp[NV];
-            return point_to_world<MD::hand_link>(q, cs, sn, {{T(MD::hand_pos[0]), T(MD::hand_pos[1]), T(MD::hand_pos[2])}}, tmp);
+            return point_to_world<MD::hand_link>(q, fr, {{T(MD::hand_pos[0]), T(MD::hand_pos[1]), T(MD::hand_pos[2])}}, tmp);
         } else {
             return {{T(0), T(0), T(0)}};
         }
     }
 
     // actuation (clamped to the control range), joint damping and bias forces
-    static MPPI_HD void smooth_force(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV],
+    static MPPI_HD void smooth_force(const T (&q)[NQ], const Frames& fr, const T (&qd)[NV],
                                      const T (&ctrl)[NV], T (&fs)[NV]) {
         T bias[NV];
-        bias_forces(q, cs, sn, qd, bias);
+        bias_forces(q, fr, qd, bias);
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             T u = ctrl[i];
@@ -237,7 +288,7 @@ template <class T, class MD> struct Step {
         });
     }
 
-    static MPPI_HD void build_rows(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], Rows& r) {
+    static MPPI_HD void build_rows(const T (&q)[NQ], const Frames& fr, const T (&qd)[NV], Rows& r) {
         r.any = Mask<T>{};
         // joint limits: at most one side can be violated; evaluated without branches.  A row deeper than
         // the impedance ramp (solimp width) has the constant impedance dmax, so its weight is a constant of
@@ -249,8 +300,9 @@ template <class T, class MD> struct Step {
             constexpr int i = Ic;
             r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1); pos[i] = T(0);
             if constexpr (MD::limited[i] != 0) {
-                const T lo = q[i] - T(MD::range_lo[i]);
-                const T hi = T(MD::range_hi[i]) - q[i];
+                static_assert(!is_ball(i), "ball joints have no limit rows");
+                const T lo = q[MD::qadr[i]] - T(MD::range_lo[i]);
+                const T hi = T(MD::range_hi[i]) - q[MD::qadr[i]];
                 const Mask<T> blo = lo < hi;
                 pos[i] = sel(blo, lo, hi);
                 r.sg[i] = sel(blo, T(1), T(-1));
@@ -287,7 +339,7 @@ template <class T, class MD> struct Step {
         if constexpr (MD::contact_link >= 0) {
             constexpr int L = MD::contact_link;
             Vec3<T> xc[NV];
-            const Vec3<T> cw = point_to_world<L>(q, cs, sn, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
+            const Vec3<T> cw = point_to_world<L>(q, fr, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
             const T dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
             const Mask<T> near = dist < T(MD::contact_margin);
             if (any_of(near)) {
@@ -303,7 +355,7 @@ template <class T, class MD> struct Step {
                         Vec3<T> zp;
                         if constexpr (p < 0) zp = {{T(0), T(0), T(1)}};
                         else zp = zl[p];
-                        zl[i] = to_child<A>(cs[i], sn[i], zp);
+                        zl[i] = down<i>(fr, zp);
                         // (e_A x x)[U] = -x[W], (e_A x x)[W] = x[U]
                         r.Jc[i] = sel(near, T(MD::axis_sign[i]) * (zl[i].v[W] * xc[i].v[U] - zl[i].v[U] * xc[i].v[W]), T(0));
                         vel += r.Jc[i] * qd[i];
@@ -404,34 +456,55 @@ template <class T, class MD> struct Step {
         sweeps_out = sweeps;
     }
 
-    // v += h a with (M + h B) a = fs + fc, then q += h v
-    static MPPI_HD void integrate(const DampedFactor& f, const T (&fs)[NV], const T (&fc)[NV], T (&q)[NV], T (&qd)[NV]) {
+    // v += h a with (M + h B) a = fs + fc, then q += h v; a ball joint's quaternion is turned by the new angular
+    // velocity (body frame) over h and renormalised
+    static MPPI_HD void integrate(const DampedFactor& f, const T (&fs)[NV], const T (&fc)[NV], T (&q)[NQ], T (&qd)[NV]) {
         T qacc[NV];
         static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
         chol_apply(f.L, f.inv, qacc);
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
+            constexpr int a = MD::qadr[i];
             qd[i] = qd[i] + T(MD::H) * qacc[i];
-            q[i] = q[i] + T(MD::H) * qd[i];
+            if constexpr (MD::jtype[i] == 4) {               // a ball is integrated at its last link, all three rates known
+                constexpr int i0 = i - 2;
+                const T wx = qd[i0], wy = qd[i0 + 1], wz = qd[i0 + 2];
+                const T n2 = wx * wx + wy * wy + wz * wz;
+                const T n = sqrt_t(n2);
+                const T half_angle = T(0.5 * MD::H) * n;
+                T sh, ch;
+                sincos_t(half_angle, sh, ch);
+                const T g = sel(n2 > T(1e-24), sh * rcp_t(sel(n2 > T(1e-24), n, T(1))), T(0.5 * MD::H));      // sin(h n / 2) / n
+                const T dx = g * wx, dy = g * wy, dz = g * wz;
+                const T qw = q[a], qx = q[a + 1], qy = q[a + 2], qz = q[a + 3];
+                const T r0 = qw * ch - qx * dx - qy * dy - qz * dz;
+                const T r1 = qw * dx + qx * ch + qy * dz - qz * dy;
+                const T r2 = qw * dy - qx * dz + qy * ch + qz * dx;
+                const T r3 = qw * dz + qx * dy - qy * dx + qz * ch;
+                const T inv = rsqrt_t(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+                q[a] = r0 * inv; q[a + 1] = r1 * inv; q[a + 2] = r2 * inv; q[a + 3] = r3 * inv;
+            } else if constexpr (!is_ball(i)) {
+                q[a] = q[a] + T(MD::H) * qd[i];
+            }
         });
     }
 
     // (q, v, ctrl) -> (q', v') in place.
     //   want_hand : also evaluate the end-effector site at the input q
     //   act       : see constraint_forces
-    static MPPI_HD void substep(T (&q)[NV], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
+    static MPPI_HD void substep(T (&q)[NQ], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
                                 Active& act, int& sweeps_out) {
-        T cs[NV], sn[NV];
-        trig(q, cs, sn);
+        Frames fr;
+        frames(q, fr);
         if constexpr (MD::hand_link >= 0) {
-            if (want_hand) out.hand = hand_site(q, cs, sn);
+            if (want_hand) out.hand = hand_site(q, fr);
         }
         T fs[NV];
-        smooth_force(q, cs, sn, qd, ctrl, fs);
+        smooth_force(q, fr, qd, ctrl, fs);
         T M[NV][NV];     // lower triangle used: M[i][j], i >= j
-        mass_matrix(q, cs, sn, M);
+        mass_matrix(q, fr, M);
         Rows rows;
-        build_rows(q, cs, sn, qd, rows);
+        build_rows(q, fr, qd, rows);
         DampedFactor f;
         T fc[NV];
         constraint_forces(M, fs, rows, act, fc, sweeps_out, f);
@@ -441,10 +514,11 @@ template <class T, class MD> struct Step {
     // bias forces: recursive Newton-Euler with zero joint acceleration, link-local coordinates.
     // Velocity and velocity-product acceleration travel as pairs, angular {omega, alpha} and linear {v, a}
     // (same transforms, same inertia products); force and moment travel back as a pair too.
-    static MPPI_HD void bias_forces(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const T (&qd)[NV], T (&bias)[NV]) {
+    static MPPI_HD void bias_forces(const T (&q)[NQ], const Frames& fr, const T (&qd)[NV], T (&bias)[NV]) {
         using P = Pair<T>;
         Vec3<P> ang[NV], lin[NV];       // [0]: velocity, [1]: acceleration
         Vec3<P> fm[NV];                 // [0]: force, [1]: moment about the link origin
+        Vec3<T> wc[NV], vc[NV];         // velocity that carries the joint axis (see below)
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             constexpr int p = MD::parent[i];
@@ -457,22 +531,28 @@ template <class T, class MD> struct Step {
                 l = a;
                 // gravity enters as an upward acceleration of the world
                 if constexpr (MD::has_gravity) {
-                    const Vec3<T> g = to_child<A>(cs[i], sn[i], Vec3<T>{{T(-MD::gravity[0]), T(-MD::gravity[1]), T(-MD::gravity[2])}});
+                    const Vec3<T> g = down<i>(fr, Vec3<T>{{T(-MD::gravity[0]), T(-MD::gravity[1]), T(-MD::gravity[2])}});
                     static_for<3>([&](auto Cn) { l.v[Cn][1] = g.v[Cn]; });
                 }
             } else {
-                a = to_child<A>(cs[i], sn[i], ang[p]);
-                l = to_child<A>(cs[i], sn[i], add(lin[p], cross(ang[p], r)));
+                a = down<i>(fr, ang[p]);
+                l = down<i>(fr, add(lin[p], cross(ang[p], r)));
             }
-            // joint rate along / about axis A; velocity-product acceleration V x (S qd)
+            // joint rate along / about axis A; velocity-product acceleration V x (S qd), V the velocity that carries
+            // the axis: the parent's for a hinge or slide.  The three axes of a ball joint are fixed in the body;
+            // summed over the joint that is the same as carrying all three with the velocity in front of the ball
+            // (the joint's own rate crossed with itself vanishes), which the first link of the ball hands on.
             Vec3<T> sq = {{T(0), T(0), T(0)}};
             sq.v[A] = T(MD::axis_sign[i]) * qd[i];
+            const Vec3<T> wcar = [&]() -> Vec3<T> { if constexpr (MD::jtype[i] >= 3) return wc[p]; else return half<T>(a, 0); }();
+            const Vec3<T> vcar = [&]() -> Vec3<T> { if constexpr (MD::jtype[i] >= 3) return vc[p]; else return half<T>(l, 0); }();
+            if constexpr (MD::jtype[i] >= 2) { wc[i] = wcar; vc[i] = vcar; }      // handed on inside a ball joint only
             if constexpr (MD::jtype[i] == 1) {
-                const Vec3<T> da = cross(half<T>(a, 0), sq);
+                const Vec3<T> da = cross(wcar, sq);
                 static_for<3>([&](auto Cn) { l.v[Cn][1] += da.v[Cn]; });
                 l.v[A][0] += sq.v[A];
             } else {
-                const Vec3<T> dw = cross(half<T>(a, 0), sq), dv = cross(half<T>(l, 0), sq);
+                const Vec3<T> dw = cross(wcar, sq), dv = cross(vcar, sq);
                 static_for<3>([&](auto Cn) { a.v[Cn][1] += dw.v[Cn]; l.v[Cn][1] += dv.v[Cn]; });
                 a.v[A][0] += sq.v[A];
             }
@@ -495,10 +575,10 @@ template <class T, class MD> struct Step {
             bias[i] = T(MD::axis_sign[i]) * fm[i].v[A][MD::jtype[i] == 1 ? 0 : 1];
             if constexpr (p >= 0) {
                 const Vec3<T> r = off_<i>(q);
-                const Vec3<P> up = to_parent<A>(cs[i], sn[i], fm[i]);
-                const Vec3<T> rf = cross(r, half<T>(up, 0));
+                const Vec3<P> par = up<i>(fr, fm[i]);
+                const Vec3<T> rf = cross(r, half<T>(par, 0));
                 static_for<3>([&](auto Cn) {
-                    fm[p].v[Cn] += up.v[Cn];
+                    fm[p].v[Cn] += par.v[Cn];
                     fm[p].v[Cn][1] += rf.v[Cn];
                 });
             }
@@ -506,7 +586,7 @@ template <class T, class MD> struct Step {
     }
 
     // joint-space inertia (lower triangle, armature included): composite rigid bodies in link coordinates
-    static MPPI_HD void mass_matrix(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], T (&M)[NV][NV]) {
+    static MPPI_HD void mass_matrix(const T (&q)[NQ], const Frames& fr, T (&M)[NV][NV]) {
         SpInertia<T> Ic_[NV];
         // joints on different branches do not couple
         static_for<NV>([&](auto In) {
@@ -542,24 +622,41 @@ template <class T, class MD> struct Step {
                 if constexpr (p >= 0) {
                     Vec3<Pair<T>> fm;
                     static_for<3>([&](auto Cn) { fm.v[Cn] = make_pair_of(f.v[Cn], n.v[Cn]); });
-                    walk_up<i, i>(q, cs, sn, fm, M);
+                    walk_up<i, i>(q, fr, fm, M);
                 }
             }
             if constexpr (p >= 0) {
                 // express composite i in the parent frame and add it to the parent's composite
-                const T c = cs[i], s = sn[i];
                 const T* I = Ic_[i].I;
-                const Vec3<T> h = to_parent<A>(c, s, Ic_[i].h);
+                const Vec3<T> h = up<i>(fr, Ic_[i].h);
                 T J[6];
-                const T cc = c * c, ss = s * s, sc = s * c;
-                const T Iuu = I[sym_idx(U, U)], Iww = I[sym_idx(W, W)], Iuw = I[sym_idx(U, W)];
-                const T Iau = I[sym_idx(A, U)], Iaw = I[sym_idx(A, W)];
-                J[sym_idx(A, A)] = I[sym_idx(A, A)];
-                J[sym_idx(A, U)] = c * Iau - s * Iaw;
-                J[sym_idx(A, W)] = s * Iau + c * Iaw;
-                J[sym_idx(U, U)] = cc * Iuu - T(2) * sc * Iuw + ss * Iww;
-                J[sym_idx(W, W)] = ss * Iuu + T(2) * sc * Iuw + cc * Iww;
-                J[sym_idx(U, W)] = sc * (Iuu - Iww) + (cc - ss) * Iuw;
+                if constexpr (MD::jtype[i] == 2) {
+                    // J = R I R^T with a full rotation matrix
+                    const T (&R)[9] = rb_of<decltype(Icn)::value>(fr);
+                    T RI[3][3];
+                    static_for<3>([&](auto Rn) {
+                        static_for<3>([&](auto Cn) {
+                            RI[Rn][Cn] = R[3 * Rn] * I[sym_idx(0, Cn)] + R[3 * Rn + 1] * I[sym_idx(1, Cn)] + R[3 * Rn + 2] * I[sym_idx(2, Cn)];
+                        });
+                    });
+                    static_for<3>([&](auto Rn) {
+                        static_for<3 - Rn>([&](auto Dn) {
+                            constexpr int c2 = Rn + Dn;
+                            J[sym_idx(Rn, c2)] = RI[Rn][0] * R[3 * c2] + RI[Rn][1] * R[3 * c2 + 1] + RI[Rn][2] * R[3 * c2 + 2];
+                        });
+                    });
+                } else {
+                    const T c = fr.cs(i), s = fr.sn(i);
+                    const T cc = c * c, ss = s * s, sc = s * c;
+                    const T Iuu = I[sym_idx(U, U)], Iww = I[sym_idx(W, W)], Iuw = I[sym_idx(U, W)];
+                    const T Iau = I[sym_idx(A, U)], Iaw = I[sym_idx(A, W)];
+                    J[sym_idx(A, A)] = I[sym_idx(A, A)];
+                    J[sym_idx(A, U)] = c * Iau - s * Iaw;
+                    J[sym_idx(A, W)] = s * Iau + c * Iaw;
+                    J[sym_idx(U, U)] = cc * Iuu - T(2) * sc * Iuw + ss * Iww;
+                    J[sym_idx(W, W)] = ss * Iuu + T(2) * sc * Iuw + cc * Iww;
+                    J[sym_idx(U, W)] = sc * (Iuu - Iww) + (cc - ss) * Iuw;
+                }
                 const Vec3<T> r = off_<i>(q);
                 const T m = Ic_[i].m;
                 const T rr = r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2];
@@ -581,16 +678,16 @@ template <class T, class MD> struct Step {
 
     // carry the pair {force, moment about the origin of link I} of column COL up the tree, filling M[COL][ancestor]
     template <int COL, int I>
-    static MPPI_HD void walk_up(const T (&q)[NV], const T (&cs)[NV], const T (&sn)[NV], const Vec3<Pair<T>>& fm, T (&M)[NV][NV]) {
+    static MPPI_HD void walk_up(const T (&q)[NQ], const Frames& fr, const Vec3<Pair<T>>& fm, T (&M)[NV][NV]) {
         constexpr int p = MD::parent[I];
         if constexpr (p >= 0) {
             constexpr int A = MD::axis_id[I];
             const Vec3<T> r = off_<I>(q);
-            Vec3<Pair<T>> up = to_parent<A>(cs[I], sn[I], fm);
-            const Vec3<T> rf = cross(r, half<T>(up, 0));
-            static_for<3>([&](auto Cn) { up.v[Cn][1] += rf.v[Cn]; });
-            M[COL][p] = T(MD::axis_sign[p]) * up.v[MD::axis_id[p]][MD::jtype[p] == 1 ? 0 : 1];
-            walk_up<COL, p>(q, cs, sn, up, M);
+            Vec3<Pair<T>> par = up<I>(fr, fm);
+            const Vec3<T> rf = cross(r, half<T>(par, 0));
+            static_for<3>([&](auto Cn) { par.v[Cn][1] += rf.v[Cn]; });
+            M[COL][p] = T(MD::axis_sign[p]) * par.v[MD::axis_id[p]][MD::jtype[p] == 1 ? 0 : 1];
+            walk_up<COL, p>(q, fr, par, M);
         }
     }
 

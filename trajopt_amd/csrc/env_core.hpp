@@ -24,7 +24,7 @@ template <class T> struct RewardParams {
 // miscompiled by ROCm 7.2's hipcc (wrong values that change from build to build); as a
 // function of its own it matches the fp64 oracle to rounding.  fp32 stays inline.
 template <class MD>
-__device__ __noinline__ void substep_outofline(double (&q)[MD::NV], double (&qd)[MD::NV], const double (&act)[MD::NV],
+__device__ __noinline__ void substep_outofline(double (&q)[MD::NQ], double (&qd)[MD::NV], const double (&act)[MD::NV],
                                                bool want_hand, typename Step<double, MD>::Out& o,
                                                typename Step<double, MD>::Active& rows, int& sw) {
     Step<double, MD>::substep(q, qd, act, want_hand, o, rows, sw);
@@ -53,7 +53,7 @@ template <class T, class MD> struct Env {
         return T(-10) * dist - T(0.25) * vn;
     }
 
-    static MPPI_HD T step(T (&q)[NV], T (&qd)[NV], const T (&act)[NV], const RewardParams<T>& rp, const T* ref_row,
+    static MPPI_HD T step(T (&q)[MD::NQ], T (&qd)[NV], const T (&act)[NV], const RewardParams<T>& rp, const T* ref_row,
                           Vec3<T>& hand, typename S::Active& rows, int& max_sweeps) {
         typename S::Out o;
         o.hand = {{T(0), T(0), T(0)}};

@@ -183,8 +183,8 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
                const double* __restrict__ ref, int K, int H, int reward_type, double gamma, int explicit_act,
                T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status,
                T* __restrict__ fobs, int* __restrict__ next_step) {
-    constexpr int NV = MD::NV;
-    constexpr int OD = 2 * NV + 6;
+    constexpr int NV = MD::NV, NQ = MD::NQ;
+    constexpr int OD = NQ + NV + 6;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     // index of the planning step after this one, for a noise generator that runs while the state advances
@@ -196,8 +196,9 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         if (rew) rew += pl * K * H;
         if (fobs) fobs += pl * K * OD;
     }
-    T q[NV], v[NV];
-    static_for<NV>([&](auto Ic) { q[Ic] = T(st->q[Ic]); v[Ic] = T(st->v[Ic]); });
+    T q[NQ], v[NV];
+    static_for<NQ>([&](auto Ic) { q[Ic] = T(st->q[Ic]); });
+    static_for<NV>([&](auto Ic) { v[Ic] = T(st->v[Ic]); });
     RewardParams<T> rp;
     rp.type = reward_type;
     rp.alpha = T(st->alpha);
@@ -235,41 +236,46 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         g *= gm;
         if (fobs && t == H - 1) {
             T* o = fobs + (size_t)k * OD;
-            static_for<NV>([&](auto Ic) { o[Ic] = q[Ic]; o[NV + Ic] = v[Ic]; });
-            o[2 * NV + 0] = hand.v[0]; o[2 * NV + 1] = hand.v[1]; o[2 * NV + 2] = hand.v[2];
-            o[2 * NV + 3] = rp.target[0]; o[2 * NV + 4] = rp.target[1]; o[2 * NV + 5] = rp.target[2];
+            static_for<NQ>([&](auto Ic) { o[Ic] = q[Ic]; });
+            static_for<NV>([&](auto Ic) { o[NQ + Ic] = v[Ic]; });
+            o[NQ + NV + 0] = hand.v[0]; o[NQ + NV + 1] = hand.v[1]; o[NQ + NV + 2] = hand.v[2];
+            o[NQ + NV + 3] = rp.target[0]; o[NQ + NV + 4] = rp.target[1]; o[NQ + NV + 5] = rp.target[2];
         }
         if (rew) rew[(size_t)k * H + t] = r;
         if (obs) {
             T* o = obs + ((size_t)k * H + t) * OD;
-            static_for<NV>([&](auto Ic) { o[Ic] = q[Ic]; o[NV + Ic] = v[Ic]; });
-            o[2 * NV + 0] = hand.v[0]; o[2 * NV + 1] = hand.v[1]; o[2 * NV + 2] = hand.v[2];
-            o[2 * NV + 3] = rp.target[0]; o[2 * NV + 4] = rp.target[1]; o[2 * NV + 5] = rp.target[2];
+            static_for<NQ>([&](auto Ic) { o[Ic] = q[Ic]; });
+            static_for<NV>([&](auto Ic) { o[NQ + Ic] = v[Ic]; });
+            o[NQ + NV + 0] = hand.v[0]; o[NQ + NV + 1] = hand.v[1]; o[NQ + NV + 2] = hand.v[2];
+            o[NQ + NV + 3] = rp.target[0]; o[NQ + NV + 4] = rp.target[1]; o[NQ + NV + 5] = rp.target[2];
         }
     }
     R[k] = ret;
     if (nonfinite(ret)) atomicOr(status, 1);
 }
 
-// one fp64 env.step of the real environment; io: in [q(nv) v(nv) target(3) act(nv) alpha refrow(3)], out [q v obs(2nv+6) reward]
+// one fp64 env.step of the real environment; io: in [q(nq) v(nv) target(3) act(nv) alpha refrow(3)],
+// out [q(nq) v(nv) obs(nq+nv+6) reward]
 template <class MD>
 __global__ void __launch_bounds__(64) env_step_kernel(const double* __restrict__ in, int reward_type, int has_ref, int forward_only,
                                 double* __restrict__ out) {
-    constexpr int NV = MD::NV;
+    constexpr int NV = MD::NV, NQ = MD::NQ, S = NQ + NV;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double q[NV], v[NV], a[NV];
-    static_for<NV>([&](auto Ic) { q[Ic] = in[Ic]; v[Ic] = in[NV + Ic]; a[Ic] = in[2 * NV + 3 + Ic]; });
+    double q[NQ], v[NV], a[NV];
+    static_for<NQ>([&](auto Ic) { q[Ic] = in[Ic]; });
+    static_for<NV>([&](auto Ic) { v[Ic] = in[NQ + Ic]; a[Ic] = in[S + 3 + Ic]; });
     RewardParams<double> rp;
     rp.type = reward_type;
-    rp.target[0] = in[2 * NV]; rp.target[1] = in[2 * NV + 1]; rp.target[2] = in[2 * NV + 2];
-    rp.alpha = in[3 * NV + 3];
-    const double* rr = in + 3 * NV + 4;
+    rp.target[0] = in[S]; rp.target[1] = in[S + 1]; rp.target[2] = in[S + 2];
+    rp.alpha = in[S + NV + 3];
+    const double* rr = in + S + NV + 4;
     Vec3<double> hand;
     double r = 0.0;
     if (forward_only) {
         // sim.forward(): kinematics only; the substep leaves q, v untouched copies
-        double q2[NV], v2[NV], z[NV];
-        static_for<NV>([&](auto Ic) { q2[Ic] = q[Ic]; v2[Ic] = v[Ic]; z[Ic] = 0.0; });
+        double q2[NQ], v2[NV], z[NV];
+        static_for<NQ>([&](auto Ic) { q2[Ic] = q[Ic]; });
+        static_for<NV>([&](auto Ic) { v2[Ic] = v[Ic]; z[Ic] = 0.0; });
         typename Step<double, MD>::Out o;
         int sw;
         typename Step<double, MD>::Active am;
@@ -282,10 +288,11 @@ __global__ void __launch_bounds__(64) env_step_kernel(const double* __restrict__
         am.reset();
         r = Env<double, MD>::step(q, v, a, rp, has_ref ? rr : nullptr, hand, am, ms);
     }
-    static_for<NV>([&](auto Ic) { out[Ic] = q[Ic]; out[NV + Ic] = v[Ic]; out[2 * NV + Ic] = q[Ic]; out[3 * NV + Ic] = v[Ic]; });
-    out[4 * NV + 0] = hand.v[0]; out[4 * NV + 1] = hand.v[1]; out[4 * NV + 2] = hand.v[2];
-    out[4 * NV + 3] = rp.target[0]; out[4 * NV + 4] = rp.target[1]; out[4 * NV + 5] = rp.target[2];
-    out[4 * NV + 6] = r;
+    static_for<NQ>([&](auto Ic) { out[Ic] = q[Ic]; out[S + Ic] = q[Ic]; });
+    static_for<NV>([&](auto Ic) { out[NQ + Ic] = v[Ic]; out[S + NQ + Ic] = v[Ic]; });
+    out[2 * S + 0] = hand.v[0]; out[2 * S + 1] = hand.v[1]; out[2 * S + 2] = hand.v[2];
+    out[2 * S + 3] = rp.target[0]; out[2 * S + 4] = rp.target[1]; out[2 * S + 5] = rp.target[2];
+    out[2 * S + 6] = r;
 }
 
 // Device-resident `advance_time` (trajopt/algos/mppi.py:67-89): lane 0 steps the real environment in fp64 with
@@ -296,8 +303,8 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
                                               const double* __restrict__ ref, int reward_type, int H, int tail_mode,
                                               const double* __restrict__ mean, double* __restrict__ log, int log_cap,
                                               int* __restrict__ log_count) {
-    constexpr int NV = MD::NV;
-    constexpr int ROW = 3 * NV + 7;
+    constexpr int NV = MD::NV, NQ = MD::NQ;
+    constexpr int ROW = NQ + 2 * NV + 7;
     constexpr int PER = 16;                       // H * NV <= 256 * PER
     const int tid = threadIdx.x;
     double keep[PER];
@@ -316,8 +323,9 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
         keep[u] = v;
     }
     if (tid == 0) {
-        double q[NV], v[NV], a[NV];
-        static_for<NV>([&](auto Ic) { q[Ic] = st->q[Ic]; v[Ic] = st->v[Ic]; a[Ic] = base[Ic]; });
+        double q[NQ], v[NV], a[NV];
+        static_for<NQ>([&](auto Ic) { q[Ic] = st->q[Ic]; });
+        static_for<NV>([&](auto Ic) { v[Ic] = st->v[Ic]; a[Ic] = base[Ic]; });
         RewardParams<double> rp;
         rp.type = reward_type;
         rp.alpha = st->alpha;
@@ -336,10 +344,11 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
         const double r = Env<double, MD>::step(q, v, a, rp, rr, hand, am, ms);
         const int n = *log_count;
         double* row = log + (size_t)(n % log_cap) * ROW;
-        static_for<NV>([&](auto Ic) { row[Ic] = q[Ic]; row[NV + Ic] = v[Ic]; row[2 * NV + 7 + Ic] = a[Ic]; st->q[Ic] = q[Ic]; st->v[Ic] = v[Ic]; });
-        row[2 * NV + 0] = hand.v[0]; row[2 * NV + 1] = hand.v[1]; row[2 * NV + 2] = hand.v[2];
-        row[2 * NV + 3] = rp.target[0]; row[2 * NV + 4] = rp.target[1]; row[2 * NV + 5] = rp.target[2];
-        row[2 * NV + 6] = r;
+        static_for<NQ>([&](auto Ic) { row[Ic] = q[Ic]; st->q[Ic] = q[Ic]; });
+        static_for<NV>([&](auto Ic) { row[NQ + Ic] = v[Ic]; row[NQ + NV + 7 + Ic] = a[Ic]; st->v[Ic] = v[Ic]; });
+        row[NQ + NV + 0] = hand.v[0]; row[NQ + NV + 1] = hand.v[1]; row[NQ + NV + 2] = hand.v[2];
+        row[NQ + NV + 3] = rp.target[0]; row[NQ + NV + 4] = rp.target[1]; row[NQ + NV + 5] = rp.target[2];
+        row[NQ + NV + 6] = r;
         st->timestep = t0 + 1;
         *log_count = n + 1;
     }
@@ -637,7 +646,7 @@ struct RolloutArgs {
 
 struct ModelOps {
     const char* name;
-    int nv;
+    int nv, nq;
     bool (*matches)(const mppi_model_desc*, std::string&);
     hipError_t (*rollout)(int dtype, const RolloutArgs&, hipStream_t);
     hipError_t (*noise_upload)(int dtype, const double* raw, int K, int H, int P, const FilterCoefs&, int filter, void* eps, hipStream_t);
@@ -661,6 +670,7 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
 #define CHK(cond, what)                                                                     \
     if (!(cond)) { why = std::string("model field differs from the compiled kernel: ") + what; return false; }
     CHK(d->nv == NV, "nv");
+    CHK(d->nq == MD::NQ, "nq");
     CHK(d->frame_skip == MD::FRAME_SKIP, "frame_skip");
     CHK(near(d->h, MD::H), "timestep");
     CHK(d->contact_link == MD::contact_link, "contact_link");
@@ -668,6 +678,7 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
     for (int i = 0; i < NV; i++) {
         CHK(d->parent[i] == MD::parent[i], "parent");
         CHK(d->jtype[i] == MD::jtype[i], "joint type");
+        CHK(d->qadr[i] == MD::qadr[i], "qpos address");
         CHK((d->limited[i] != 0) == (MD::limited[i] != 0), "limited");
         const double m = d->mass[i];
         for (int c = 0; c < 3; c++) {
@@ -801,10 +812,10 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
     return hipGetLastError();
 }
 template <class MD> static ModelOps make_ops() {
-    return {MD::name, MD::NV, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
+    return {MD::name, MD::NV, MD::NQ, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
             &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_advance_noise<MD>, &launch_update_rows<MD>};
 }
-static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>()};
+static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>(), make_ops<Tree18DofQuat>()};
 
 // ------------------------------------------------------------------------------------------
 // handles
@@ -819,7 +830,7 @@ struct mppi_model {
 struct mppi_planner {
     const mppi_model* model;
     mppi_planner_cfg cfg;
-    int nv, HM, P;         // P = planners batched in this handle (arrays below carry a leading [P])
+    int nv, nq, HM, P;         // P = planners batched in this handle (arrays below carry a leading [P])
     size_t esz;            // sizeof(T)
     hipStream_t stream;
     DevState* d_state;
@@ -897,12 +908,13 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     p->model = m;
     p->cfg = *cfg;
     p->nv = m->ops->nv;
+    p->nq = m->ops->nq;
     p->HM = cfg->H * p->nv;
     p->P = cfg->P > 1 ? cfg->P : 1;
     p->cfg.P = p->P;
     p->esz = cfg->dtype == MPPI_F32 ? 4 : 8;
     const size_t P = p->P;
-    const size_t K = cfg->K * P, HM = p->HM * P, OD = 2 * p->nv + 6;   // sizes over all planners
+    const size_t K = cfg->K * P, HM = p->HM * P, OD = p->nq + p->nv + 6;   // sizes over all planners
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_OK(hipMalloc(&p->d_state, sizeof(DevState) * P));
     HIP_OK(hipMemset(p->d_state, 0, sizeof(DevState) * P));
@@ -921,7 +933,7 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     HIP_OK(hipMemset(p->d_result, 0, 2 * 8 * P));
     HIP_OK(hipMalloc(&p->d_status, 4));
     HIP_OK(hipMemset(p->d_status, 0, 4));
-    HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (3 * p->nv + 7) * 8));
+    HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (p->nq + 2 * p->nv + 7) * 8));
     HIP_OK(hipMalloc(&p->d_log_count, 4 * P));
     HIP_OK(hipMemset(p->d_log_count, 0, 4 * P));
     HIP_OK(hipMalloc(&p->d_next_step, 4 * P));
@@ -968,7 +980,8 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
     // alpha / ref_len come from the host mirror; q, v, target, timestep are replaced
     std::vector<DevState>& s = *p->h_state;
     for (int b = 0; b < p->P; b++) {
-        for (int i = 0; i < p->nv; i++) { s[b].q[i] = qpos[b * p->nv + i]; s[b].v[i] = qvel[b * p->nv + i]; }
+        for (int i = 0; i < p->nq; i++) s[b].q[i] = qpos[b * p->nq + i];
+        for (int i = 0; i < p->nv; i++) s[b].v[i] = qvel[b * p->nv + i];
         for (int c = 0; c < 3; c++) s[b].target[c] = target3[3 * b + c];
         s[b].timestep = timestep[b];
     }
@@ -1031,7 +1044,7 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
     std::memcpy(o, W3, CRITIC_INNER * 4); o += CRITIC_INNER;
     *o = b3;
     if (!p->d_critic) HIP_OK(hipMalloc(&p->d_critic, CRITIC_W_FLOATS * 4));
-    if (!p->d_fobs) HIP_OK(hipMalloc(&p->d_fobs, (size_t)p->cfg.K * p->P * (2 * p->nv + 6) * p->esz));
+    if (!p->d_fobs) HIP_OK(hipMalloc(&p->d_fobs, (size_t)p->cfg.K * p->P * (p->nq + p->nv + 6) * p->esz));
     HIP_OK(hipMemcpy(p->d_critic, w.data(), CRITIC_W_FLOATS * 4, hipMemcpyHostToDevice));
     p->critic_dim = dim;
     return 0;
@@ -1099,7 +1112,7 @@ int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_ro
     HIP_OK(hipDeviceSynchronize());
     int count = 0;
     HIP_OK(hipMemcpy(&count, p->d_log_count + planner, 4, hipMemcpyDeviceToHost));
-    const int row = 3 * p->nv + 7;
+    const int row = p->nq + 2 * p->nv + 7;
     const double* ring = p->d_log + (size_t)planner * MPPI_LOG_CAP * row;
     int n = count < MPPI_LOG_CAP ? count : MPPI_LOG_CAP;
     if (n > max_rows) n = max_rows;
@@ -1375,7 +1388,7 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) {
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
     // every selector returns the P planners of the handle back to back
-    const size_t P = p->P, K = p->cfg.K, H = p->cfg.H, HM = p->HM, OD = 2 * p->nv + 6;
+    const size_t P = p->P, K = p->cfg.K, H = p->cfg.H, HM = p->HM, OD = p->nq + p->nv + 6;
     auto need = [&](size_t n) { return bytes == n; };
     switch (what) {
     case MPPI_READ_RETURNS:
@@ -1418,7 +1431,7 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) {
     }
     case MPPI_READ_NEXT_OBS:
         if (!p->d_obs) return fail(-4, "planner was created without cfg.dump");
-        if (!need(P * K * H * OD * 8)) return fail(-1, "NEXT_OBS needs P*K*H*(2M+6) doubles");
+        if (!need(P * K * H * OD * 8)) return fail(-1, "NEXT_OBS needs P*K*H*(nq+nv+6) doubles");
         return read_as_double(p, p->d_obs, P * K * H * OD, (double*)dst);
     case MPPI_READ_REWARDS:
         if (!p->d_rew) return fail(-4, "planner was created without cfg.dump");
@@ -1451,46 +1464,45 @@ int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const
     if (!m || !qpos || !qvel || !target3 || !act) return fail(-1, "null argument");
     if ((reward_type == MPPI_REWARD_TRACKING || reward_type == MPPI_REWARD_COOLING) && (!ref || T < 1))
         return fail(-1, "tracking / cooling reward needs a reference");
-    const int nv = m->ops->nv;
+    const int nv = m->ops->nv, nq = m->ops->nq, ns = nq + nv;
     double* io;
     int rc = env_io(m, device, &io);
     if (rc) return rc;
     double in[4 * MPPI_MAXV + 16];
-    for (int i = 0; i < nv; i++) { in[i] = qpos[i]; in[nv + i] = qvel[i]; in[2 * nv + 3 + i] = act[i]; }
-    for (int c = 0; c < 3; c++) in[2 * nv + c] = target3[c];
-    in[3 * nv + 3] = alpha;
+    for (int i = 0; i < nq; i++) in[i] = qpos[i];
+    for (int i = 0; i < nv; i++) { in[nq + i] = qvel[i]; in[ns + 3 + i] = act[i]; }
+    for (int c = 0; c < 3; c++) in[ns + c] = target3[c];
+    in[ns + nv + 3] = alpha;
     const int has_ref = ref && T > 0;
     if (has_ref) {
         if (timestep + 1 >= T) return fail(-5, "reference index out of range");   // IndexError in the reference
-        for (int c = 0; c < 3; c++) in[3 * nv + 4 + c] = ref[3 * (timestep + 1) + c];
+        for (int c = 0; c < 3; c++) in[ns + nv + 4 + c] = ref[3 * (timestep + 1) + c];
     }
-    const int n_in = 3 * nv + 7, n_out = 4 * nv + 7;
+    const int n_in = ns + nv + 7, n_out = 2 * ns + 7;
     HIP_OK(hipMemcpy(io, in, n_in * 8, hipMemcpyHostToDevice));
     HIP_OK(m->ops->env_step(io, reward_type, has_ref, 0, io + 256, 0));
     double out[4 * MPPI_MAXV + 16];
     HIP_OK(hipMemcpy(out, io + 256, n_out * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < nv; i++) {
-        if (qpos_out) qpos_out[i] = out[i];
-        if (qvel_out) qvel_out[i] = out[nv + i];
-    }
-    if (obs_out) for (int i = 0; i < 2 * nv + 6; i++) obs_out[i] = out[2 * nv + i];
-    if (reward_out) *reward_out = out[4 * nv + 6];
+    if (qpos_out) for (int i = 0; i < nq; i++) qpos_out[i] = out[i];
+    if (qvel_out) for (int i = 0; i < nv; i++) qvel_out[i] = out[nq + i];
+    if (obs_out) for (int i = 0; i < ns + 6; i++) obs_out[i] = out[ns + i];
+    if (reward_out) *reward_out = out[2 * ns + 6];
     return 0;
 }
 
 int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, double* hand3_out) {
     if (!m || !qpos || !hand3_out) return fail(-1, "null argument");
-    const int nv = m->ops->nv;
+    const int nv = m->ops->nv, nq = m->ops->nq, ns = nq + nv;
     double* io;
     int rc = env_io(m, device, &io);
     if (rc) return rc;
     double in[4 * MPPI_MAXV + 16] = {0};
-    for (int i = 0; i < nv; i++) in[i] = qpos[i];
-    HIP_OK(hipMemcpy(io, in, (3 * nv + 7) * 8, hipMemcpyHostToDevice));
+    for (int i = 0; i < nq; i++) in[i] = qpos[i];
+    HIP_OK(hipMemcpy(io, in, (ns + nv + 7) * 8, hipMemcpyHostToDevice));
     HIP_OK(m->ops->env_step(io, 0, 0, 1, io + 256, 0));
     double out[4 * MPPI_MAXV + 16];
-    HIP_OK(hipMemcpy(out, io + 256, (4 * nv + 7) * 8, hipMemcpyDeviceToHost));
-    for (int c = 0; c < 3; c++) hand3_out[c] = out[4 * nv + c];
+    HIP_OK(hipMemcpy(out, io + 256, (2 * ns + 7) * 8, hipMemcpyDeviceToHost));
+    for (int c = 0; c < 3; c++) hand3_out[c] = out[2 * ns + c];
     return 0;
 }
 

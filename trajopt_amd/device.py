@@ -19,6 +19,7 @@ class DeviceModel:
     def __init__(self, md: ModelDesc):
         self.md = md
         self.nv = md.nv
+        self.nq = md.nq
         self._h = L._vp()
         self._c = L.desc_to_c(md)
         L.check(L.lib().mppi_model_create(C.byref(self._c), C.byref(self._h)))
@@ -31,12 +32,12 @@ class DeviceModel:
 
     def env_step(self, qpos, qvel, target, act, timestep=0, reward_type="dense", reference=None, alpha=1.0,
                  device=None):
-        """One fp64 `env.step` on the device -> (qpos', qvel', obs[2nv+6], reward)."""
-        nv = self.nv
+        """One fp64 `env.step` on the device -> (qpos', qvel', obs[nq+nv+6], reward)."""
+        nv, nq = self.nv, self.nq
         qpos, qvel, target, act = L.f64(qpos), L.f64(qvel), L.f64(target), L.f64(act)
-        assert qpos.shape == (nv,) and qvel.shape == (nv,) and act.shape == (nv,) and target.shape == (3,)
+        assert qpos.shape == (nq,) and qvel.shape == (nv,) and act.shape == (nv,) and target.shape == (3,)
         ref = None if reference is None else L.f64(reference)
-        q2, v2, obs = np.empty(nv), np.empty(nv), np.empty(2 * nv + 6)
+        q2, v2, obs = np.empty(nq), np.empty(nv), np.empty(nq + nv + 6)
         r = C.c_double(0.0)
         rc = L.lib().mppi_env_step(self._h, default_device() if device is None else device, L.ptr(qpos), L.ptr(qvel),
                                    L.ptr(target), L.ptr(act), int(timestep), L.REWARD_TYPES[reward_type],
@@ -74,7 +75,7 @@ class DevicePlanner:
                  dump=False, planners=1):
         """planners > 1 batches that many independent planners (own start state, base actions, noise
         stream, log) in one handle: every per-planner array gains a leading axis of that size."""
-        self.model, self.K, self.H, self.nv = model, int(K), int(H), model.nv
+        self.model, self.K, self.H, self.nv, self.nq = model, int(K), int(H), model.nv, model.nq
         self.P = int(planners)
         self.dtype = dtype
         cfg = L.PlannerCfgC()
@@ -115,7 +116,7 @@ class DevicePlanner:
     def set_start_state(self, qpos, qvel, target, timestep=0):
         qpos, qvel, target = L.f64(qpos), L.f64(qvel), L.f64(target)
         ts = np.ascontiguousarray(np.broadcast_to(np.asarray(timestep, dtype=np.int32), (self.P,)))
-        assert qpos.shape == self._lead(self.nv) and qvel.shape == self._lead(self.nv) and target.shape == self._lead(3)
+        assert qpos.shape == self._lead(self.nq) and qvel.shape == self._lead(self.nv) and target.shape == self._lead(3)
         L.check(L.lib().mppi_set_start_state(self._h, L.ptr(qpos), L.ptr(qvel), L.ptr(target), L.ptr(ts)))
 
     def set_base_actions(self, act):
@@ -169,13 +170,14 @@ class DevicePlanner:
 
     def read_log(self, max_rows=4096, planner=0):
         """Most recent rows of one planner's real-env log, oldest first: dict of arrays + total count."""
-        nv = self.nv
-        rows = np.empty((max_rows, 3 * nv + 7))
+        nv, nq = self.nv, self.nq
+        rows = np.empty((max_rows, nq + 2 * nv + 7))
         n, total = C.c_int32(), C.c_int32()
         L.check(L.lib().mppi_read_log(self._h, int(planner), L.ptr(rows), int(max_rows), C.byref(n), C.byref(total)))
         r = rows[:n.value]
-        return dict(qpos=r[:, :nv], qvel=r[:, nv:2 * nv], hand=r[:, 2 * nv:2 * nv + 3], target=r[:, 2 * nv + 3:2 * nv + 6],
-                    reward=r[:, 2 * nv + 6], action=r[:, 2 * nv + 7:], total=total.value)
+        s = nq + nv
+        return dict(qpos=r[:, :nq], qvel=r[:, nq:s], hand=r[:, s:s + 3], target=r[:, s + 3:s + 6],
+                    reward=r[:, s + 6], action=r[:, s + 7:], total=total.value)
 
     def upload_actions(self, act):
         act = L.f64(act)
@@ -250,7 +252,7 @@ class DevicePlanner:
         return self._read(L.READ_ACTIONS, self._lead(self.K, self.H, self.nv))
 
     def next_observations(self):
-        return self._read(L.READ_NEXT_OBS, self._lead(self.K, self.H, 2 * self.nv + 6))
+        return self._read(L.READ_NEXT_OBS, self._lead(self.K, self.H, self.nq + self.nv + 6))
 
     def rewards(self):
         return self._read(L.READ_REWARDS, self._lead(self.K, self.H))

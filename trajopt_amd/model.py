@@ -8,9 +8,12 @@ the C ABI (``mppi_model_desc`` in ``include/mppi_hip.h``) and (b) baked into
 the HIP kernels as compile-time constants by ``tools/gen_model_header.py``.
 
 Covered subset of the model language: bodies without orientation offsets, hinge
-and slide joints at the body origin (several per body compose in order, which is
-how a floating base is written: three slides then three hinges), sphere / capsule /
-plane geoms, sites, motors with gear and ctrlrange, gravity, Euler integrator.
+slide, ball and free joints at the body origin (several per body compose in order),
+sphere / capsule / plane geoms, sites, motors with gear and ctrlrange, gravity, Euler
+integrator.  A ball joint keeps its orientation as a unit quaternion in qpos (nq = nv + 1
+per ball) and its velocity as the angular velocity in the body frame, like the free and
+ball joints of the reference's simulator; a free joint is three world-aligned slides and
+a ball.
 """
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -18,7 +21,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 DENSITY = 1000.0  # default geom density
-HINGE, SLIDE = 0, 1
+HINGE, SLIDE, BALL_X, BALL_Y, BALL_Z = 0, 1, 2, 3, 4     # a ball joint is three links in one frame
 
 
 # --------------------------------------------------------------------------
@@ -43,7 +46,7 @@ class Joint:
     limited: bool = True
     gear: float = 10.0
     ctrlrange: Tuple[float, float] = (-1.0, 1.0)
-    kind: str = "hinge"                         # 'hinge' | 'slide'
+    kind: str = "hinge"                         # 'hinge' | 'slide' | 'ball' (quaternion) | 'free' (3 slides + ball)
 
 
 @dataclass
@@ -144,6 +147,16 @@ def tree_18dof_spec() -> ModelSpec:
     return ModelSpec("tree_18dof", 0.005, 1, [trunk], gravity=(0.0, 0.0, -9.81))
 
 
+def tree_18dof_quat_spec() -> ModelSpec:
+    """`tree_18dof` with a true free joint on the trunk: position and unit quaternion in qpos (nq = 19),
+    linear velocity in the world frame and angular velocity in the trunk frame in qvel (nv = 18)."""
+    s = tree_18dof_spec()
+    s.name = "tree_18dof_quat"
+    trunk = s.root[0]
+    trunk.joints = [Joint((0, 0, 1), kind="free", damping=0.0, armature=0.0, gear=0.0, limited=False, range=(0.0, 0.0))]
+    return s
+
+
 def strip_constraints(spec: ModelSpec) -> ModelSpec:
     """Copy of ``spec`` with joint limits and collisions removed (the 'no contacts' arm)."""
     import copy
@@ -234,14 +247,32 @@ class ModelDesc:
     solref_k: float
     solref_b: float
     solimp: np.ndarray        # (5,)
-    jtype: np.ndarray = None  # (nv,) int32: 0 hinge, 1 slide
+    jtype: np.ndarray = None  # (nv,) int32: 0 hinge, 1 slide, 2/3/4 x/y/z component of a ball joint
     gravity: np.ndarray = None  # (3,)
+    nq: int = None            # length of qpos: nv + number of ball joints
+    qadr: np.ndarray = None   # (nv,) int32: qpos index of the joint's coordinate (a ball's three links: its quaternion w)
 
     def __post_init__(self):
         if self.jtype is None:
             self.jtype = np.zeros(self.nv, np.int32)
         if self.gravity is None:
             self.gravity = np.zeros(3)
+        if self.qadr is None:
+            adr, n = [], 0
+            for t in self.jtype:
+                if t == BALL_X:
+                    adr.append(n); n += 4
+                elif t in (BALL_Y, BALL_Z):
+                    adr.append(adr[-1])
+                else:
+                    adr.append(n); n += 1
+            self.qadr, self.nq = np.asarray(adr, np.int32), n
+
+    def qpos0(self):
+        """Reference configuration: zeros, unit quaternions."""
+        q = np.zeros(self.nq)
+        q[self.qadr[self.jtype == BALL_X]] = 1.0
+        return q
 
     def link_inertia_matrix(self, i):
         xx, yy, zz, xy, xz, yz = self.inertia[i]
@@ -254,6 +285,12 @@ def _rot(axis, ang):
     return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
 
 
+def _quat_rot(w, x, y, z):
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
 def mass_matrix(md: ModelDesc, q):
     """Joint-space inertia (with armature) by the composite-body method; host-side
     helper used by the model compiler for the constraint weights."""
@@ -263,12 +300,18 @@ def mass_matrix(md: ModelDesc, q):
         pi = md.parent[i]
         Rp = np.eye(3) if pi < 0 else R[pi]
         pp = np.zeros(3) if pi < 0 else p[pi]
+        a = md.qadr[i]
         if md.jtype[i] == SLIDE:
-            p[i] = pp + Rp @ (md.pos[i] + q[i] * md.axis[i])
+            p[i] = pp + Rp @ (md.pos[i] + q[a] * md.axis[i])
             R[i] = Rp
+        elif md.jtype[i] == BALL_X:
+            p[i] = pp + Rp @ md.pos[i]
+            R[i] = Rp @ _quat_rot(*q[a:a + 4])
+        elif md.jtype[i] in (BALL_Y, BALL_Z):
+            p[i], R[i] = pp, Rp                      # same frame as the ball's first link
         else:
             p[i] = pp + Rp @ md.pos[i]
-            R[i] = Rp @ _rot(md.axis[i], q[i])
+            R[i] = Rp @ _rot(md.axis[i], q[a])
     # spatial inertia about the world origin: (m, m*c, I_O)
     m = md.mass.copy(); hc = np.zeros((nv, 3)); IO = np.zeros((nv, 3, 3))
     S = np.zeros((nv, 6))
@@ -325,7 +368,22 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
             for ch in body.children:
                 visit(ch, parent_link, off)
             return
-        # one link per joint; the body's geoms ride on the last one, the others are massless
+        # one link per degree of freedom; the body's geoms ride on the last one, the others are massless
+        import dataclasses
+        prim = []
+        for jn in joints:
+            unit = lambda k, kind: dataclasses.replace(jn, axis=tuple(float(c == k) for c in range(3)), kind=kind)
+            if jn.kind == "free":
+                prim += [unit(k, "slide") for k in range(3)]
+            if jn.kind in ("free", "ball"):
+                if jn.limited:
+                    raise ValueError("limited ball joints are not supported")
+                prim += [unit(0, "ball_x"), unit(1, "ball_y"), unit(2, "ball_z")]
+            elif jn.kind in ("hinge", "slide"):
+                prim.append(jn)
+            else:
+                raise ValueError("joint kind %r" % (jn.kind,))
+        joints = prim
         for n, jn in enumerate(joints):
             link = dict(parent=parent_link, pos=(offset_in_parent + pos) if n == 0 else np.zeros(3), joint=jn,
                         parts=[], sites={}, contact=None)
@@ -352,7 +410,8 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
         contact_plane_z=0.0, contact_margin=0.0, contact_invweight=0.0,
         hand_link=-1, hand_pos=np.zeros(3), solref_k=0.0, solref_b=0.0,
         solimp=np.asarray(spec.solimp, float),
-        jtype=np.array([SLIDE if l["joint"].kind == "slide" else HINGE for l in links], np.int32),
+        jtype=np.array([dict(hinge=HINGE, slide=SLIDE, ball_x=BALL_X, ball_y=BALL_Y, ball_z=BALL_Z)[l["joint"].kind]
+                        for l in links], np.int32),
         gravity=np.asarray(spec.gravity, float))
     contact_body = None
     for i, l in enumerate(links):
@@ -385,7 +444,7 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
     md.solref_b = 2.0 / (dmax * tc)
 
     # constraint weights at the reset pose q = 0
-    M0, (R, p) = mass_matrix(md, np.zeros(nv))
+    M0, (R, p) = mass_matrix(md, md.qpos0())
     Minv = np.linalg.inv(M0)
     md.dof_invweight = np.diag(Minv).copy()
     if md.contact_link >= 0:
@@ -426,6 +485,8 @@ def get_model(name: str) -> ModelDesc:
             _CACHE[name] = compile_model(strip_constraints(reacher_7dof_spec()))
         elif name == "tree_18dof":
             _CACHE[name] = compile_model(tree_18dof_spec())
+        elif name == "tree_18dof_quat":
+            _CACHE[name] = compile_model(tree_18dof_quat_spec())
         else:
             raise KeyError(name)
     return _CACHE[name]

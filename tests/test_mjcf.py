@@ -74,8 +74,67 @@ def test_planar_double_pendulum_matches_closed_form():
 def test_unsupported_features_are_rejected():
     for bad, what in ((PLANAR.replace('integrator="Euler"', 'integrator="RK4"'), "integrator"),
                       (PLANAR.replace('<body name="lower" pos="0 0 -0.5">', '<body name="lower" pos="0 0 -0.5" quat="1 0 0 0">'), "orientation"),
-                      (PLANAR.replace('type="hinge" axis="0 1 0"/>\n      <geom type="sphere" size="0.05"', 'type="ball"/>\n      <geom type="sphere" size="0.05"'), "joint type"),
+                      (PLANAR.replace('name="j1" type="hinge"', 'name="j1" type="screw"'), "joint type"),
+                      (PLANAR.replace('name="j0" type="hinge" axis="0 1 0"', 'name="j0" type="ball"'), "motors on ball"),
                       (PLANAR.replace('angle="radian"', 'angle="degree"'), "radian"),
                       (PLANAR.replace('joint="j0"', 'joint="nope"'), "unknown joints")):
         with pytest.raises(ValueError, match=what):
             load_mjcf(bad, "x", 1)
+
+
+FLOATING = """
+<mujoco model="floating">
+  <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
+  <option timestep="0.0005" gravity="0 0 -9.81" integrator="Euler"/>
+  <default><geom contype="0" conaffinity="0"/></default>
+  <worldbody>
+    <body name="hull" pos="0 0 1">
+      <freejoint/>
+      <geom type="capsule" size="0.05" fromto="-0.2 0 0 0.2 0 0"/>
+      <geom type="sphere" size="0.06" pos="0.05 0.1 0.02"/>
+      <body name="pendant" pos="0.2 0 0">
+        <joint name="b" type="ball"/>
+        <geom type="capsule" size="0.03" fromto="0 0 0 0 0.1 -0.3"/>
+        <site name="finger" pos="0 0.1 -0.3"/>
+      </body>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def test_free_and_ball_joints_from_xml():
+    """<freejoint/> and type="ball": position + quaternion coordinates, and under the oracle the total
+    linear momentum follows gravity while the spin angular momentum about the centre of mass is kept."""
+    import dataclasses
+    from oracle.sim import OracleSim
+    from test_oracle_tree import _momenta
+    md = compile_model(load_mjcf(FLOATING, "floating", frame_skip=1))
+    assert md.nv == 9 and md.nq == 11
+    assert list(md.jtype) == [1, 1, 1, 2, 3, 4, 2, 3, 4] and list(md.qadr) == [0, 1, 2, 3, 3, 3, 7, 7, 7]
+    q0 = md.qpos0()
+    assert np.array_equal(q0, [0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])
+    rs = np.random.RandomState(2)
+    q = q0.copy()
+    for a in (3, 7):
+        quat = rs.randn(4)
+        q[a:a + 4] = quat / np.linalg.norm(quat)
+    v = rs.randn(md.nv)
+    sim = OracleSim(md)
+    mtot = md.mass.sum()
+    P0, L0 = _momenta(md, q, v)
+    n = 400
+    for k in range(n):
+        q, v, _, _ = sim.substep(q, v, np.zeros(md.nv))
+    P1, L1 = _momenta(md, q, v)
+    want = P0 + mtot * md.gravity * md.h * n
+    assert np.abs(P1 - want).max() < 2e-3 * np.abs(want).max()
+    # without gravity the angular momentum about the origin is kept (first order in h)
+    md0 = dataclasses.replace(md, gravity=np.zeros(3))
+    sim = OracleSim(md0)
+    P0, L0 = _momenta(md0, q, v)
+    for k in range(n):
+        q, v, _, _ = sim.substep(q, v, np.zeros(md.nv))
+    P1, L1 = _momenta(md0, q, v)
+    assert np.abs(L1 - L0).max() < 5e-3 * np.abs(L0).max() and np.abs(P1 - P0).max() < 1e-3 * np.abs(P0).max()
+    assert abs(np.linalg.norm(q[3:7]) - 1) < 1e-12 and abs(np.linalg.norm(q[7:11]) - 1) < 1e-12

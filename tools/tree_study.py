@@ -2,7 +2,9 @@
 """Precision and timing study on the synthetic 18-DoF floating-base tree at K = 32768, H = 128:
 fp32 rollouts against fp64 rollouts of the same Philox noise (relative state error
 |x32 - x64| / (1 + |x64|), worst coordinate per sample, at t = 32 / 64 / 128), and the
-rollout-kernel time of both.  Writes one JSON object (stdout, and the path given as argv[1])."""
+rollout-kernel time of both.  Writes one JSON object (stdout, and the path given as argv[1]).
+argv[2] names the model: tree_18dof (default; Euler-angle base) or tree_18dof_quat (quaternion base, same
+start pose and velocity: the error then covers position, the four quaternion components and velocities)."""
 import json
 import os
 import sys
@@ -19,6 +21,16 @@ def run(model, dtype, dump, reps):
     p = DevicePlanner(model, K, H, kappa=5.0, gamma=0.99, sigma=np.ones(NV), betas=(0.25, 0.8, 0.0), dtype=dtype, dump=dump)
     rs = np.random.RandomState(3)
     q0 = np.r_[0.0, 0.0, 0.0, rs.randn(15) * 0.3]
+    if model.nq > NV:
+        # the same trunk attitude as the successive x, y, z hinges of the other model
+        ax, ay, az = q0[3:6]
+        hx = np.r_[np.cos(ax / 2), np.sin(ax / 2), 0, 0]
+        hy = np.r_[np.cos(ay / 2), 0, np.sin(ay / 2), 0]
+        hz = np.r_[np.cos(az / 2), 0, 0, np.sin(az / 2)]
+
+        def qmul(a, b):
+            return np.r_[a[0] * b[0] - a[1:] @ b[1:], a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:])]
+        q0 = np.r_[q0[:3], qmul(qmul(hx, hy), hz), q0[6:]]
     p.set_start_state(q0, rs.randn(NV) * 0.3, np.array([0.4, 0.1, 0.8]), 0)
     p.set_base_actions(np.zeros((H, NV)))
     p.generate_noise(2024)
@@ -34,14 +46,16 @@ def run(model, dtype, dump, reps):
 
 
 def main():
-    model = DeviceModel.get("tree_18dof")
-    out = dict(model="tree_18dof", K=K, H=H, frame_skip=1, noise="philox seed 2024")
+    name = sys.argv[2] if len(sys.argv) > 2 else "tree_18dof"
+    model = DeviceModel.get(name)
+    ND = model.nq + NV
+    out = dict(model=name, K=K, H=H, frame_skip=1, noise="philox seed 2024")
     p64, t64 = run(model, "f64", True, 3)
-    o64 = p64.next_observations()[..., :2 * NV]
+    o64 = p64.next_observations()[..., :ND]
     R64 = p64.returns()
     p64.close()
     p32, t32d = run(model, "f32", True, 3)
-    o32 = p32.next_observations()[..., :2 * NV]
+    o32 = p32.next_observations()[..., :ND]
     R32 = p32.returns()
     status = p32.status()
     p32.close()

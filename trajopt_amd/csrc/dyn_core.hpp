@@ -397,11 +397,6 @@ template <class T, class MD> struct Step {
             T dg[NV], dc = act.row[NV] * r.Dc;
             static_for<NV>([&](auto Ic) { dg[Ic] = act.row[Ic] * r.Dl[Ic]; });
             T acc[NV], resl[NV], resc = T(0);
-            const bool wave_contact = wave_any(r.Dc > T(0));
-            auto right_hand_side = [&]() {
-                static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + r.sg[Ic] * dg[Ic] * r.arl[Ic]; });
-                if (wave_contact) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
-            };
             // residual signs decide the next active set; true if this lane's set changed
             auto settle = [&]() -> Mask<T> {
                 Mask<T> changed{};
@@ -424,20 +419,29 @@ template <class T, class MD> struct Step {
                 }
                 return changed;
             };
-            sweeps = 1;
-            right_hand_side();
             T hb[NV];
             static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::H * MD::damping[Ic]); });
-            if (wave_contact) chol_solve_and_factor<true>(M, dg, dc, r.Jc, acc, hb, damped.L, damped.inv);
-            else chol_solve_and_factor<false>(M, dg, T(0), r.Jc, acc, hb, damped.L, damped.inv);
-            Mask<T> changed = settle();
-            while (wave_any(changed) && sweeps < 12) {
-                sweeps++;
+            // the sweeps exist twice, with and without the contact row, chosen once per substep: a taken
+            // branch costs a lone wave about as much as a dozen vector instructions
+            auto sweep_all = [&](auto Wc) {
+                constexpr bool WC = decltype(Wc)::value;
+                auto right_hand_side = [&]() {
+                    static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + r.sg[Ic] * dg[Ic] * r.arl[Ic]; });
+                    if constexpr (WC) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
+                };
+                sweeps = 1;
                 right_hand_side();
-                if (wave_contact) chol_solve<true>(M, dg, dc, r.Jc, acc);
-                else chol_solve<false>(M, dg, T(0), r.Jc, acc);
-                changed = settle();
-            }
+                chol_solve_and_factor<WC>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.L, damped.inv);
+                Mask<T> changed = settle();
+                while (wave_any(changed) && sweeps < 12) {
+                    sweeps++;
+                    right_hand_side();
+                    chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                    changed = settle();
+                }
+            };
+            if (wave_any(r.Dc > T(0))) sweep_all(std::true_type{});
+            else sweep_all(std::false_type{});
             static_for<NV>([&](auto Ic) {
                 constexpr int i = Ic;
                 if constexpr (MD::limited[i] != 0) fc[i] = -r.sg[i] * dg[i] * resl[i];

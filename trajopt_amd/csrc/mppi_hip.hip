@@ -210,13 +210,14 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     act_rows.reset();
     // the next step's noise and base action are fetched one step ahead: they do not depend on the
     // state, and a lone wave has nobody to hide a load's latency behind
-    T e_nx[NV];
-    double b_nx[NV];
-    static_for<NV>([&](auto Jc) { e_nx[Jc] = eps[(size_t)Jc * K + k]; b_nx[Jc] = base[Jc]; });
+    T a[NV];
+    static_for<NV>([&](auto Jc) { a[Jc] = explicit_act ? eps[(size_t)Jc * K + k] : T(base[Jc]) + eps[(size_t)Jc * K + k]; });
     for (int t = 0; t < H; t++) {
-        T a[NV];
-        static_for<NV>([&](auto Jc) { a[Jc] = explicit_act ? e_nx[Jc] : T(b_nx[Jc]) + e_nx[Jc]; });
+        // issued here, first touched after the step: a use at the top of the next iteration would make the
+        // wave wait for the scalar loads right behind their issue (the wait for the pre-loop loads sits there)
         const int tn = (t + 1 < H) ? t + 1 : t;
+        T e_nx[NV];
+        double b_nx[NV];
         static_for<NV>([&](auto Jc) {
             constexpr int j = Jc;
             e_nx[j] = eps[((size_t)tn * NV + j) * K + k];
@@ -234,6 +235,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         // with a terminal-value critic the last reward is replaced by the critic's value (added by critic_kernel)
         if (!(fobs && t == H - 1)) ret += g * r;
         g *= gm;
+        static_for<NV>([&](auto Jc) { a[Jc] = explicit_act ? e_nx[Jc] : T(b_nx[Jc]) + e_nx[Jc]; });
         if (fobs && t == H - 1) {
             T* o = fobs + (size_t)k * OD;
             static_for<NQ>([&](auto Ic) { o[Ic] = q[Ic]; });

@@ -6,7 +6,9 @@ The reference passes its XML asset to the simulator (`trajopt/envs/mujoco_env.py
     <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
     <option timestep gravity integrator="Euler"/>
     <default> <joint .../> <geom .../> <motor .../> </default>      (top-level defaults only)
-    <worldbody> nested <body pos> with <joint type="hinge|slide" axis range damping armature limited>,
+    <worldbody> nested <body pos> with <joint type="hinge|slide|ball|free" axis range damping armature limited>
+                or <freejoint/> (free: position + unit quaternion in qpos, world-frame linear and body-frame
+                angular velocity in qvel; ball: quaternion only),
                 <geom type="sphere|capsule|plane" size pos fromto contype conaffinity margin>, <site name pos>
     <actuator> <motor joint gear ctrlrange/> </actuator>
 
@@ -100,8 +102,17 @@ def load_mjcf(source, name, frame_skip, hand_site="finger") -> ModelSpec:
     def joint(e):
         a = _merged(defaults["joint"], e)
         kind = a.get("type", "hinge")
-        if kind not in ("hinge", "slide"):
-            raise ValueError("joint type %r has no kernel (hinge and slide only)" % kind)
+        if kind not in ("hinge", "slide", "ball", "free"):
+            raise ValueError("joint type %r is not a joint type of the format" % kind)
+        if kind in ("ball", "free"):
+            if a.get("limited", "false") == "true":
+                raise ValueError("limited %s joints have no kernel" % kind)
+            if a.get("name") in motors:
+                raise ValueError("motors on %s joints have no kernel" % kind)
+            if kind == "free" and (float(a.get("damping", 0.0)) != 0.0 or float(a.get("armature", 0.0)) != 0.0):
+                raise ValueError("free joints take no damping or armature")
+            return Joint(axis=(0.0, 0.0, 1.0), range=(0.0, 0.0), damping=float(a.get("damping", 0.0)),
+                         armature=float(a.get("armature", 0.0)), limited=False, gear=0.0, kind=kind)
         if any(abs(x) > 0 for x in _floats(a.get("pos", "0 0 0"), 3)):
             raise ValueError("joints must sit at the body origin")
         jn = a.get("name")
@@ -124,7 +135,8 @@ def load_mjcf(source, name, frame_skip, hand_site="finger") -> ModelSpec:
             if c.tag == "joint":
                 joints.append(joint(c))
             elif c.tag == "freejoint":
-                raise ValueError("free joints have no kernel; write three slides and three hinges")
+                joints.append(Joint(axis=(0.0, 0.0, 1.0), range=(0.0, 0.0), damping=0.0, armature=0.0, limited=False,
+                                    gear=0.0, kind="free"))
             elif c.tag == "geom":
                 geoms.append(geom(c))
             elif c.tag == "site":

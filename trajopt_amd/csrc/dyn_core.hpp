@@ -91,6 +91,11 @@ MPPI_HD bool wave_any(bool x) {
 #endif
 }
 
+// Layout hints for wave-uniform branches: the expected side becomes the fall-through path.  A taken branch
+// costs a wave that owns its SIMD roughly ten vector instructions' time; one that falls through, next to none.
+#define MPPI_LIKELY(x) __builtin_expect(!!(x), 1)
+#define MPPI_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 // keeps the instruction scheduler from moving work across this point (device only)
 MPPI_HD void sched_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -310,7 +315,7 @@ template <class T, class MD> struct Step {
                 ramp |= (pos[i] < T(0)) & (pos[i] > T(-MD::solimp[2]));
             }
         });
-        if (wave_any(ramp)) {
+        if (MPPI_UNLIKELY(wave_any(ramp))) {
             static_for<NV>([&](auto Ic) {
                 constexpr int i = Ic;
                 if constexpr (MD::limited[i] != 0) {
@@ -342,7 +347,7 @@ template <class T, class MD> struct Step {
             const Vec3<T> cw = point_to_world<L>(q, fr, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
             const T dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
             const Mask<T> near = dist < T(MD::contact_margin);
-            if (any_of(near)) {
+            if (MPPI_UNLIKELY(wave_any(near))) {       // uniform over the wave; lanes away from the plane get zeros
                 // d(z of the sphere centre)/dq_i = z_i . (axis_i x x_i): world z axis and the point, both in link-i coordinates
                 Vec3<T> zl[NV];
                 T vel = T(0);
@@ -392,7 +397,7 @@ template <class T, class MD> struct Step {
                                           T (&fc)[NV], int& sweeps_out, DampedFactor& damped) {
         static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
         int sweeps = 0;
-        if (wave_any(r.any)) {
+        if (MPPI_LIKELY(wave_any(r.any))) {
             // active weight of every row: its D while active, 0 while inactive or absent
             T dg[NV], dc = act.row[NV] * r.Dc;
             static_for<NV>([&](auto Ic) { dg[Ic] = act.row[Ic] * r.Dl[Ic]; });
@@ -440,7 +445,7 @@ template <class T, class MD> struct Step {
                     changed = settle();
                 }
             };
-            if (wave_any(r.Dc > T(0))) sweep_all(std::true_type{});
+            if (MPPI_UNLIKELY(wave_any(r.Dc > T(0)))) sweep_all(std::true_type{});
             else sweep_all(std::false_type{});
             static_for<NV>([&](auto Ic) {
                 constexpr int i = Ic;

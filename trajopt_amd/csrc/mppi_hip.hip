@@ -177,13 +177,21 @@ __device__ __forceinline__ bool nonfinite(double x) {
     return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
 }
 
-template <class T, class MD>
+// LEAN: the planning configuration (dense reward, noise-relative samples, nothing dumped, no reference, no
+// critic) with those choices fixed at compile time: a lone wave pays about ten vector instructions' time for
+// every taken branch, and the general kernel spends eight per env step on options that are off.
+template <class T, class MD, bool LEAN>
 __global__ void __launch_bounds__(64)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
-               const double* __restrict__ ref, int K, int H, int reward_type, double gamma, int explicit_act,
-               T* __restrict__ R, T* __restrict__ obs, T* __restrict__ rew, int* __restrict__ status,
-               T* __restrict__ fobs, int* __restrict__ next_step) {
+               const double* __restrict__ ref, int K, int H, int reward_type_, double gamma, int explicit_act_,
+               T* __restrict__ R, T* __restrict__ obs_, T* __restrict__ rew_, int* __restrict__ status,
+               T* __restrict__ fobs_, int* __restrict__ next_step) {
     constexpr int NV = MD::NV, NQ = MD::NQ;
+    const int reward_type = LEAN ? int(REWARD_DENSE) : reward_type_;
+    const int explicit_act = LEAN ? 0 : explicit_act_;
+    T* __restrict__ obs = LEAN ? nullptr : obs_;
+    T* __restrict__ rew = LEAN ? nullptr : rew_;
+    T* __restrict__ fobs = LEAN ? nullptr : fobs_;
     constexpr int OD = NQ + NV + 6;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
@@ -203,7 +211,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     rp.type = reward_type;
     rp.alpha = T(st->alpha);
     rp.target[0] = T(st->target[0]); rp.target[1] = T(st->target[1]); rp.target[2] = T(st->target[2]);
-    const int t0 = st->timestep, ref_len = st->ref_len;
+    const int t0 = st->timestep, ref_len = LEAN ? 0 : st->ref_len;
     const T gm = T(gamma);
     T ret = T(0), g = T(1);
     typename Step<T, MD>::Active act_rows;
@@ -643,6 +651,7 @@ __global__ void __launch_bounds__(256) update_direct_kernel(const double* __rest
 struct RolloutArgs {
     const DevState* st; const double* base; const void* eps; const double* ref;
     int K, H, P, reward_type; double gamma; int explicit_act;
+    bool lean;      // dense reward, noise-relative samples, no dumps, no reference, no critic
     void* R; void* obs; void* rew; int* status; void* fobs; int* next_step;
 };
 
@@ -722,11 +731,14 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
 
 template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArgs& a, hipStream_t s) {
     const dim3 grid((a.K + 63) / 64, a.P), block(64);      // one wave per block: waves spread over CUs and XCDs
-    if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((rollout_kernel<float, MD>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
+    if (dtype == MPPI_F32 && a.lean)
+        hipLaunchKernelGGL((rollout_kernel<float, MD, true>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step);
+    else if (dtype == MPPI_F32)
+        hipLaunchKernelGGL((rollout_kernel<float, MD, false>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
                            a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step);
     else
-        hipLaunchKernelGGL((rollout_kernel<double, MD>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
+        hipLaunchKernelGGL((rollout_kernel<double, MD, false>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
                            a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs, a.next_step);
     return hipGetLastError();
 }
@@ -1020,6 +1032,7 @@ int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alp
         s[b].alpha = alpha; s[b].ref_len = T;
         (*p->h_state)[b].alpha = alpha; (*p->h_state)[b].ref_len = T;
     }
+    p->graph_valid = false;       // a captured rollout may be the kernel variant without a reference
     HIP_OK(hipMemcpy(p->d_state, s.data(), sizeof(DevState) * p->P, hipMemcpyHostToDevice));
     return 0;
 }
@@ -1155,6 +1168,9 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
     a.R = p->d_R; a.obs = p->d_obs; a.rew = p->d_rew; a.status = p->d_status;
     a.fobs = p->critic_dim ? p->d_fobs : nullptr;
     a.next_step = p->d_next_step;
+    bool has_ref = false;
+    for (int b = 0; b < p->P; b++) has_ref |= (*p->h_state)[b].ref_len > 0;
+    a.lean = a.reward_type == REWARD_DENSE && !a.explicit_act && !a.obs && !a.rew && !a.fobs && !has_ref;
     HIP_OK(p->model->ops->rollout(p->cfg.dtype, a, s));
     if (p->profiling) {
         HIP_OK(hipEventRecord(e1, s));

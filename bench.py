@@ -212,7 +212,7 @@ def main():
                        "K_per_gpu": K_PER_GPU, "K_total": world * K_PER_GPU, "H": H, "frame_skip": 2, "niter": 1,
                        "parallelism": "samples sharded %d-way, one all-gather of %d doubles per rank per step"
                                       % (world, 3 + H * M) if world > 1 else "single GPU"},
-            "roofline": {"bound": "valu", "kernel": "rollout_kernel<float, Reacher7Dof>",
+            "roofline": {"bound": "valu", "kernel": "rollout_kernel<float, Reacher7Dof, true>",
                          "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": measured_traffic(),
                          "flop_per_env_step": flops, "kernel_ms": k_ms, "launches": launches,

@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-KERNEL = "rollout_kernel<float, mppi::Reacher7Dof>"
+KERNEL = "rollout_kernel<float, mppi::Reacher7Dof,"      # both variants (general, planning-only)
 K, H, NV, FRAME_SKIP = 4096, 64, 7, 2
 
 

@@ -438,11 +438,14 @@ template <class T, class MD> struct Step {
                 right_hand_side();
                 chol_solve_and_factor<WC>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.L, damped.inv);
                 Mask<T> changed = settle();
-                while (wave_any(changed) && sweeps < 12) {
-                    sweeps++;
-                    right_hand_side();
-                    chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
-                    changed = settle();
+                // a set carried over from the previous substep is usually confirmed by the first sweep
+                if (MPPI_UNLIKELY(wave_any(changed))) {
+                    do {
+                        sweeps++;
+                        right_hand_side();
+                        chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                        changed = settle();
+                    } while (wave_any(changed) && sweeps < 12);
                 }
             };
             if (MPPI_UNLIKELY(wave_any(r.Dc > T(0)))) sweep_all(std::true_type{});

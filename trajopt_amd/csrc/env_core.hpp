@@ -57,19 +57,30 @@ template <class T, class MD> struct Env {
                           Vec3<T>& hand, typename S::Active& rows, int& max_sweeps) {
         typename S::Out o;
         o.hand = {{T(0), T(0), T(0)}};
-#if defined(__clang__)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (std::is_same<T, double>::value) {
 #pragma nounroll
-#endif
+            for (int s = 0; s < MD::FRAME_SKIP; s++) {
+                int sw;
+                substep_outofline<MD>(q, qd, act, s == MD::FRAME_SKIP - 1, o, rows, sw);
+                max_sweeps = sw > max_sweeps ? sw : max_sweeps;
+            }
+        } else {
+            // fp32: the substeps are laid out one after the other (no loop branch, the end-effector site only in
+            // the last one)
+            static_for<MD::FRAME_SKIP>([&](auto Sc) {
+                int sw;
+                S::substep(q, qd, act, Sc == MD::FRAME_SKIP - 1, o, rows, sw);
+                max_sweeps = sw > max_sweeps ? sw : max_sweeps;
+            });
+        }
+#else
         for (int s = 0; s < MD::FRAME_SKIP; s++) {
             int sw;
-#if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (std::is_same<T, double>::value) substep_outofline<MD>(q, qd, act, s == MD::FRAME_SKIP - 1, o, rows, sw);
-            else S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, rows, sw);
-#else
             S::substep(q, qd, act, s == MD::FRAME_SKIP - 1, o, rows, sw);
-#endif
             max_sweeps = sw > max_sweeps ? sw : max_sweeps;
         }
+#endif
         hand = o.hand;
         return reward(rp, hand, qd, ref_row);
     }

@@ -829,7 +829,11 @@ template <class MD> static ModelOps make_ops() {
     return {MD::name, MD::NV, MD::NQ, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
             &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_advance_noise<MD>, &launch_update_rows<MD>};
 }
+#if defined(MPPI_ONLY_REACHER)      // quick builds for kernel experiments (make quick / make quickasm)
+static const ModelOps g_ops[] = {make_ops<Reacher7Dof>()};
+#else
 static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>(), make_ops<Tree18DofQuat>()};
+#endif
 
 // ------------------------------------------------------------------------------------------
 // handles

@@ -2,7 +2,8 @@
  *
  * The reference is pure Python and has no FFI of its own; each entry point
  * below names the reference interface it stands in for (paths relative to the
- * reference tree).  A maintainer binds these with ctypes -- see INTEGRATION.md.
+ * reference tree).  A maintainer binds these with ctypes; trajopt_amd/_lib.py
+ * holds the prototypes and structure layouts of such a binding.
  *
  * Conventions: every function returns 0 on success and a negative code on
  * failure; the message is available from mppi_last_error() (thread local,

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define MPPI_MAXV 32
-#define MPPI_ABI_VERSION 3
+#define MPPI_ABI_VERSION 4
 #define MPPI_LOG_CAP 4096
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
@@ -79,6 +79,7 @@ typedef struct mppi_model_desc {
     int32_t jtype[MPPI_MAXV];   /* 0 hinge, 1 slide along `axis`, 2/3/4 x/y/z component of a ball joint */
     int32_t nq;                 /* length of qpos: nv + one per ball joint (unit quaternion w, x, y, z)  */
     int32_t qadr[MPPI_MAXV];    /* qpos index of the joint coordinate; a ball's three links: its quaternion */
+    int32_t integrator;         /* 0 semi-implicit Euler with implicit joint damping, 1 fourth-order Runge-Kutta */
 } mppi_model_desc;
 
 /* Planner configuration: the constructor arguments of `MPPI.__init__`

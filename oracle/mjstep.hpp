@@ -58,6 +58,7 @@ struct Model {               // mirrors trajopt_amd.model.ModelDesc (flat, row-m
     int jtype[MAXV];           // 0 hinge, 1 slide (translation along `axis`), 2/3/4 x/y/z component of a ball joint
     int nq;                    // length of qpos: nv + number of ball joints
     int qadr[MAXV];            // qpos index of the joint coordinate; a ball's three links: its quaternion (w, x, y, z)
+    int integrator;            // 0 semi-implicit Euler (joint damping implicit), 1 fourth-order Runge-Kutta
 };
 constexpr int JOINT_SLIDE = 1, JOINT_BALL_X = 2, JOINT_BALL_Y = 3, JOINT_BALL_Z = 4;
 
@@ -306,12 +307,39 @@ template <class S> S impedance(const Model& md, S x) {
 
 struct StepInfo { int nrows; int nactive; int sweeps; };
 
-// one physics substep: (q, v, ctrl) -> (q', v'); also returns the end-effector
-// site position evaluated at the *input* q (what the simulator's derived
-// quantities hold after the step)
+// qpos advanced by h along a velocity: coordinates of hinges and slides move linearly, a ball's quaternion
+// turns by the body-frame rotation vector h w and is renormalised
 template <class S>
-void substep(const Model& md, const S* q, const S* v, const S* ctrl, S* q_out, S* v_out, V3<S>* hand,
-             StepInfo* info) {
+void integrate_pos(const Model& md, const S* q, const S* vel, S h, S* q_out) {
+    for (int j = 0; j < md.nv; j++) {
+        const int qa = md.qadr[j];
+        if (md.jtype[j] == JOINT_BALL_X) {
+            const S wx = vel[j], wy = vel[j + 1], wz = vel[j + 2];
+            const S n = sqrt(wx * wx + wy * wy + wz * wz);
+            const S half = S(0.5) * h * n;
+            S c = cos(half), f;                                  // f = sin(half) / n
+            if (n > S(1e-12)) f = sin(half) / n; else f = S(0.5) * h;
+            const S dw = c, dx = f * wx, dy = f * wy, dz = f * wz;
+            const S a = q[qa], b = q[qa + 1], cc = q[qa + 2], d = q[qa + 3];
+            S r0 = a * dw - b * dx - cc * dy - d * dz;
+            S r1 = a * dx + b * dw + cc * dz - d * dy;
+            S r2 = a * dy - b * dz + cc * dw + d * dx;
+            S r3 = a * dz + b * dy - cc * dx + d * dw;
+            const S inv = S(1.0) / sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+            q_out[qa] = r0 * inv; q_out[qa + 1] = r1 * inv; q_out[qa + 2] = r2 * inv; q_out[qa + 3] = r3 * inv;
+        } else if (md.jtype[j] == JOINT_BALL_Y || md.jtype[j] == JOINT_BALL_Z) {
+            continue;
+        } else {
+            q_out[qa] = q[qa] + h * vel[j];
+        }
+    }
+}
+
+// joint acceleration at (q, v, ctrl): smooth forces, constraint forces of the soft rows, and the solve with
+// M + h B (implicit_damping, the Euler step's matrix) or with M alone; also returns the end-effector site at q
+template <class S>
+void acceleration(const Model& md, const S* q, const S* v, const S* ctrl, bool implicit_damping, S* qacc,
+                  V3<S>* hand, StepInfo* info) {
     const int nv = md.nv;
     Kin<S>* k = new Kin<S>;
     Dyn<S>* d = new Dyn<S>;
@@ -412,42 +440,62 @@ void substep(const Model& md, const S* q, const S* v, const S* ctrl, S* q_out, S
     }
     if (info) { info->nrows = nrow; info->nactive = nact; info->sweeps = sweeps; }
 
-    // semi-implicit Euler, joint damping implicit
     static thread_local S B[MAXV][MAXV];
-    S qacc[MAXV];
     for (int i = 0; i < nv; i++) {
         for (int j = 0; j < nv; j++) B[i][j] = d->M[i][j];
-        B[i][i] = B[i][i] + S(md.h) * S(md.damping[i]);
+        if (implicit_damping) B[i][i] = B[i][i] + S(md.h) * S(md.damping[i]);
         qacc[i] = fs[i] + fc[i];
     }
     cholesky(B, nv);
     chol_solve(B, nv, qacc);
-    for (int j = 0; j < nv; j++) v_out[j] = v[j] + S(md.h) * qacc[j];
-    for (int j = 0; j < nv; j++) {
-        const int qa = md.qadr[j];
-        if (md.jtype[j] == JOINT_BALL_X) {
-            // q <- q * exp(h w / 2) with w the new angular velocity in the body frame, then renormalised
-            const S wx = v_out[j], wy = v_out[j + 1], wz = v_out[j + 2];
-            const S n = sqrt(wx * wx + wy * wy + wz * wz);
-            const S half = S(0.5) * S(md.h) * n;
-            S c = cos(half), f;                                  // f = sin(half) / n
-            if (n > S(1e-12)) f = sin(half) / n; else f = S(0.5) * S(md.h);
-            const S dw = c, dx = f * wx, dy = f * wy, dz = f * wz;
-            const S a = q[qa], b = q[qa + 1], cc = q[qa + 2], d = q[qa + 3];
-            S r0 = a * dw - b * dx - cc * dy - d * dz;
-            S r1 = a * dx + b * dw + cc * dz - d * dy;
-            S r2 = a * dy - b * dz + cc * dw + d * dx;
-            S r3 = a * dz + b * dy - cc * dx + d * dw;
-            const S inv = S(1.0) / sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
-            q_out[qa] = r0 * inv; q_out[qa + 1] = r1 * inv; q_out[qa + 2] = r2 * inv; q_out[qa + 3] = r3 * inv;
-        } else if (md.jtype[j] == JOINT_BALL_Y || md.jtype[j] == JOINT_BALL_Z) {
-            continue;
-        } else {
-            q_out[qa] = q[qa] + S(md.h) * v_out[j];
-        }
-    }
     delete k;
     delete d;
+}
+
+// one physics substep: (q, v, ctrl) -> (q', v'); also returns the end-effector site position the simulator's
+// derived quantities hold after the step: the one of the last configuration its dynamics were evaluated at
+// (Euler: the *input* q; Runge-Kutta: the fourth stage)
+template <class S>
+void substep(const Model& md, const S* q, const S* v, const S* ctrl, S* q_out, S* v_out, V3<S>* hand,
+             StepInfo* info) {
+    const int nv = md.nv, nq = md.nq;
+    const S h = S(md.h);
+    if (md.integrator == 0) {
+        // semi-implicit Euler, joint damping implicit
+        S qacc[MAXV];
+        acceleration(md, q, v, ctrl, true, qacc, hand, info);
+        for (int j = 0; j < nv; j++) v_out[j] = v[j] + h * qacc[j];
+        integrate_pos(md, q, v_out, h, q_out);
+        return;
+    }
+    // classical fourth-order Runge-Kutta over (qpos, qvel), the simulator's `mj_RungeKutta(4)`: stage states
+    // X_i = X_0 + h * sum_j A_ij (v_j, a_j) with A = [[1/2], [0, 1/2], [0, 0, 1]], positions advanced on the
+    // manifold (quaternions), damping explicit; result X_0 + h * sum_i b_i (v_i, a_i), b = (1, 2, 2, 1) / 6
+    S X[4][2 * MAXV + 4], F[4][MAXV];              // X_i: qpos (nq) then qvel (nv); F_i: qacc
+    for (int j = 0; j < nq; j++) X[0][j] = q[j];
+    for (int j = 0; j < nv; j++) X[0][nq + j] = v[j];
+    acceleration(md, X[0], X[0] + nq, ctrl, false, F[0], (V3<S>*)nullptr, info);
+    const double A[3] = {0.5, 0.5, 1.0};
+    for (int i = 1; i < 4; i++) {
+        S dv[MAXV];
+        for (int j = 0; j < nv; j++) {
+            dv[j] = S(A[i - 1]) * X[i - 1][nq + j];
+            X[i][nq + j] = v[j] + h * S(A[i - 1]) * F[i - 1][j];
+        }
+        for (int j = 0; j < nq; j++) X[i][j] = q[j];
+        integrate_pos(md, q, dv, h, X[i]);
+        acceleration(md, X[i], X[i] + nq, ctrl, false, F[i], i == 3 ? hand : (V3<S>*)nullptr, (StepInfo*)nullptr);
+    }
+    const double Bw[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
+    S dv[MAXV];
+    for (int j = 0; j < nv; j++) {
+        S a = S(0.0);
+        dv[j] = S(0.0);
+        for (int i = 0; i < 4; i++) { dv[j] = dv[j] + S(Bw[i]) * X[i][nq + j]; a = a + S(Bw[i]) * F[i][j]; }
+        v_out[j] = v[j] + h * a;
+    }
+    for (int j = 0; j < nq; j++) q_out[j] = q[j];
+    integrate_pos(md, q, dv, h, q_out);
 }
 
 enum RewardType { DENSE = 0, SPARSE = 1, TRACKING = 2, COOLING = 3 };

@@ -22,7 +22,7 @@ class CModel(C.Structure):
         ("dof_invweight", _d * MAXV), ("contact_pos", _d * 3), ("contact_radius", _d),
         ("contact_plane_z", _d), ("contact_margin", _d), ("contact_invweight", _d),
         ("hand_pos", _d * 3), ("solref_k", _d), ("solref_b", _d), ("solimp", _d * 5),
-        ("gravity", _d * 3), ("jtype", _i * MAXV), ("nq", _i), ("qadr", _i * MAXV),
+        ("gravity", _d * 3), ("jtype", _i * MAXV), ("nq", _i), ("qadr", _i * MAXV), ("integrator", _i),
     ]
 
 
@@ -45,6 +45,7 @@ def to_cmodel(md) -> CModel:
     m = CModel()
     m.nv, m.frame_skip, m.h = md.nv, md.frame_skip, md.h
     m.nq = int(md.nq)
+    m.integrator = int(md.integrator)
     m.contact_link, m.hand_link = md.contact_link, md.hand_link
     for i in range(md.nv):
         m.parent[i] = int(md.parent[i]); m.limited[i] = int(md.limited[i]); m.jtype[i] = int(md.jtype[i])

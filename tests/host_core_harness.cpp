@@ -44,6 +44,7 @@ extern "C" void core_rollout(int f64, int model, const double* q0, const double*
     if (model == 0) { if (f64) GO(double, Reacher7Dof); else GO(float, Reacher7Dof); }
     else if (model == 1) { if (f64) GO(double, Reacher7DofFree); else GO(float, Reacher7DofFree); }
     else if (model == 2) { if (f64) GO(double, Tree18Dof); else GO(float, Tree18Dof); }
-    else                 { if (f64) GO(double, Tree18DofQuat); else GO(float, Tree18DofQuat); }
+    else if (model == 3) { if (f64) GO(double, Tree18DofQuat); else GO(float, Tree18DofQuat); }
+    else                 { if (f64) GO(double, Tree18DofRk4); else GO(float, Tree18DofRk4); }
 }
 

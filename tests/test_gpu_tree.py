@@ -179,3 +179,55 @@ def test_quat_tree_fp32_error_growth_and_planning(treeq):
     log = p32.read_log()
     assert log["total"] == 1 and log["qpos"].shape == (1, NQ) and abs(np.linalg.norm(log["qpos"][0, 3:7]) - 1.0) < 1e-14
     p64.close(); p32.close()
+
+
+# ---- the quaternion tree stepped with fourth-order Runge-Kutta (tree_18dof_rk4) ----------------------------
+@pytest.fixture(scope="module")
+def treer():
+    from trajopt_amd.device import DeviceModel
+    return DeviceModel.get("tree_18dof_rk4")
+
+
+@pytest.fixture(scope="module")
+def treer_oracle():
+    from oracle.sim import OracleSim
+    from trajopt_amd.model import get_model
+    return OracleSim(get_model("tree_18dof_rk4"))
+
+
+def test_rk4_tree_fp64_against_oracle(treer, treer_oracle):
+    K, H = 128, 64
+    q0, v0, tgt = _start_quat()
+    p = _run(treer, "f64", K, H, q0, v0, tgt, 5)
+    act, nobs, rew, R = p.actions(), p.next_observations(), p.rewards(), p.returns()
+    assert p.status() == 0 and nobs.shape == (K, H, NQ + NV + 6)
+    R_o, nobs_o, rew_o = treer_oracle.rollout(q0, v0, tgt, 0, act, gamma=0.99, dump=True, nthreads=4)
+    assert np.abs(nobs - nobs_o).max() < 1e-8
+    assert np.abs(rew - rew_o).max() < 1e-8 and np.abs(R - R_o).max() < 1e-7
+    assert np.abs(np.linalg.norm(nobs[..., 3:7], axis=-1) - 1.0).max() < 1e-12
+    p.close()
+
+
+def test_rk4_tree_single_step_fp32_and_planning(treer, treer_oracle):
+    rs = np.random.RandomState(11)
+    for s in range(3):
+        q, v, tgt = _start_quat(30 + s)
+        a = rs.randn(NV) * 2
+        q2, v2, obs, r = treer.env_step(q, v, tgt, a, 0)
+        qo, vo, obs_o, ro, _ = treer_oracle.env_step(q, v, tgt, a)
+        assert np.abs(q2 - qo).max() < 1e-12 and np.abs(v2 - vo).max() < 1e-11
+        assert np.abs(obs - obs_o).max() < 1e-11 and abs(r - ro) < 1e-11
+    K, H = 1024, 64
+    q0, v0, tgt = _start_quat()
+    p64 = _run(treer, "f64", K, H, q0, v0, tgt, 2024)
+    p32 = _run(treer, "f32", K, H, q0, v0, tgt, 2024)
+    o64, o32 = p64.next_observations()[..., :NQ + NV], p32.next_observations()[..., :NQ + NV]
+    assert p32.status() == 0
+    rel = (np.abs(o32 - o64) / (1.0 + np.abs(o64)))[:, -1].max(axis=1)
+    print("fp32 rk4 tree error at t=64: median %.2e max %.2e" % (np.median(rel), rel.max()))
+    assert np.median(rel) < 1e-4 and rel.max() < 1e-2
+    p32.iterate(1)
+    p32.advance()
+    log = p32.read_log()
+    assert log["total"] == 1 and abs(np.linalg.norm(log["qpos"][0, 3:7]) - 1.0) < 1e-14
+    p64.close(); p32.close()

@@ -72,7 +72,7 @@ def test_planar_double_pendulum_matches_closed_form():
 
 
 def test_unsupported_features_are_rejected():
-    for bad, what in ((PLANAR.replace('integrator="Euler"', 'integrator="RK4"'), "integrator"),
+    for bad, what in ((PLANAR.replace('integrator="Euler"', 'integrator="implicit"'), "integrator"),
                       (PLANAR.replace('<body name="lower" pos="0 0 -0.5">', '<body name="lower" pos="0 0 -0.5" quat="1 0 0 0">'), "orientation"),
                       (PLANAR.replace('name="j1" type="hinge"', 'name="j1" type="screw"'), "joint type"),
                       (PLANAR.replace('name="j0" type="hinge" axis="0 1 0"', 'name="j0" type="ball"'), "motors on ball"),

@@ -182,3 +182,109 @@ def test_quaternion_integration_of_a_steady_spin(mdq):
     ang = 2.0 * np.arctan2(np.linalg.norm(q2[4:7]), q2[3])
     w_new = np.linalg.norm(v2[3:6])
     assert abs(ang - md0.h * w_new) < 1e-12 and abs(np.linalg.norm(q2[3:7]) - 1.0) < 1e-15
+
+
+# ---- fourth-order Runge-Kutta (tree_18dof_rk4) ----------------------------------------------------------
+@pytest.fixture(scope="module")
+def mdr():
+    return get_model("tree_18dof_rk4")
+
+
+def _run(md, q, v, ctrl, n):
+    sim = OracleSim(md)
+    for _ in range(n):
+        q, v, _, _ = sim.substep(q, v, ctrl)
+    return q, v
+
+
+def test_rk4_is_fourth_order(md, mdr):
+    """Halving the step divides the error at a fixed time by about 2^4 (Euler: by 2) when every coordinate is a
+    hinge angle or a slide.  Gravity, joint damping and motor torques are on; the comparison solution uses a much
+    smaller step.  With a quaternion in qpos the stages are combined in the simulator's way (one rotation by the
+    averaged angular velocity), which leaves a second-order term in the attitude: far more accurate than Euler,
+    but not fourth order."""
+    assert mdr.integrator == 1 and mdr.nq == NV + 1
+    rs = np.random.RandomState(8)
+    ctrl = rs.uniform(-1, 1, NV)
+    T = 0.08
+
+    def errors(model, q0, v0, ns, **kw):
+        ref = _run(dataclasses.replace(model, h=T / 512, integrator=1), q0, v0, ctrl, 512)
+        out = []
+        for n in ns:
+            q, v = _run(dataclasses.replace(model, h=T / n, **kw), q0, v0, ctrl, n)
+            out.append(max(np.abs(q - ref[0]).max(), np.abs(v - ref[1]).max()))
+        return out
+
+    qe, ve = np.r_[rs.randn(3) * 0.2, rs.randn(15) * 0.4], rs.randn(NV) * 0.8
+    err = errors(md, qe, ve, (4, 8, 16), integrator=1)
+    eul = errors(md, qe, ve, (16, 32), integrator=0)
+    print(err, eul)
+    assert 11.0 < err[0] / err[1] < 22.0 and 11.0 < err[1] / err[2] < 22.0, err
+    assert 1.6 < eul[0] / eul[1] < 2.4 and eul[0] > 1000 * err[2], (eul, err)
+
+    qq, vq = _random_quat_state(mdr, rs)
+    errq = errors(mdr, qq, vq, (8, 16, 32))
+    eulq = errors(mdr, qq, vq, (32,), integrator=0)
+    print(errq, eulq)
+    assert 3.5 < errq[0] / errq[1] < 22.0 and 3.5 < errq[1] / errq[2] < 22.0 and eulq[0] > 100 * errq[2], (errq, eulq)
+
+
+def test_rk4_conserves_energy_and_momentum(mdr):
+    """Free flight of the tumbling tree: linear momentum exactly, angular momentum and energy to 1e-9 over 0.2 s
+    (Euler at the same steps: 1e-3), shrinking with the step (second order: the quaternion stage rule)."""
+    rs = np.random.RandomState(9)
+    q0, v0 = _random_quat_state(mdr, rs)
+    drift = []
+    for h, n in ((4e-3, 50), (2e-3, 100)):
+        md0 = dataclasses.replace(mdr, damping=np.zeros(NV), gravity=np.zeros(3), h=h)
+        P0, L0 = _momenta(md0, q0, v0)
+        e0 = 0.5 * v0 @ mass_matrix(md0, q0)[0] @ v0
+        q, v = _run(md0, q0, v0, np.zeros(NV), n)
+        P1, L1 = _momenta(md0, q, v)
+        e1 = 0.5 * v @ mass_matrix(md0, q)[0] @ v
+        drift.append((np.abs(L1 - L0).max() / np.abs(L0).max(), abs(e1 - e0) / e0))
+        assert np.abs(P1 - P0).max() < 1e-9 * np.abs(P0).max()
+        assert abs(np.linalg.norm(q[3:7]) - 1.0) < 1e-12
+    print(drift)
+    assert drift[0][0] < 1e-8 and drift[0][1] < 1e-8
+    assert drift[1][0] < 0.3 * drift[0][0] and drift[1][1] < 0.3 * drift[0][1], drift
+
+
+def test_rk4_end_effector_is_the_fourth_stage(mdr):
+    """The site position a step reports belongs to the last configuration the dynamics saw: the fourth stage,
+    q advanced by h along the third stage's velocity."""
+    rs = np.random.RandomState(10)
+    q0, v0 = _random_quat_state(mdr, rs)
+    sim = OracleSim(mdr)
+    u = rs.uniform(-1, 1, NV)
+    _, _, hand, _ = sim.substep(q0, v0, u)
+    # stages by hand from the oracle's own Euler-free pieces: F = M^-1 (tau - bias) with explicit damping
+    def acc(q, v):
+        M, bias = sim.mass_matrix(q, v)
+        tau = mdr.gear * np.clip(u, mdr.ctrl_lo, mdr.ctrl_hi) - mdr.damping * v - bias
+        return np.linalg.solve(M, tau)
+    def ipos(vel, h):
+        e = dataclasses.replace(mdr, integrator=0, h=h, gravity=np.zeros(3), damping=np.zeros(NV), gear=np.zeros(NV))
+        # a step of a force-free copy with velocity `vel` moves q by h * vel exactly when the velocity does not
+        # change; instead integrate by hand: slides / hinges linearly, the quaternion by the rotation vector
+        q = q0.copy()
+        q[:3] += h * vel[:3]
+        w = vel[3:6]; n = np.linalg.norm(w); half = 0.5 * h * n
+        dq = np.r_[np.cos(half), np.sin(half) / n * w]
+        a, b = q0[3:7], dq
+        q[3:7] = np.r_[a[0] * b[0] - a[1:] @ b[1:], a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:])]
+        q[3:7] /= np.linalg.norm(q[3:7])
+        q[7:] += h * vel[6:]
+        return q
+    h = mdr.h
+    F0 = acc(q0, v0)
+    v1 = v0 + 0.5 * h * F0; q1 = ipos(0.5 * v0, h); F1 = acc(q1, v1)
+    v2 = v0 + 0.5 * h * F1; q2 = ipos(0.5 * v1, h); F2 = acc(q2, v2)
+    q3 = ipos(v2, h)
+    sim0 = OracleSim(mdr)
+    want = sim0.hand(q3) if hasattr(sim0, "hand") else None
+    if want is None:
+        # end-effector of a configuration: the Euler model reports the site of its input q
+        _, _, want, _ = OracleSim(dataclasses.replace(mdr, integrator=0)).substep(q3, v0, u)
+    assert np.abs(hand - want).max() < 1e-12

@@ -70,7 +70,11 @@ __global__ void __launch_bounds__(64) c_integrate(const float* in, float* out) {
     float fs[NV], fc[NV], q[NV], qd[NV];
     static_for<NV>([&](auto I) { fs[I] = IN(I); fc[I] = IN(NV + I); q[I] = IN(2 * NV + I); qd[I] = IN(3 * NV + I); f.inv[I] = IN(4 * NV + I);
                                  static_for<I>([&](auto J) { f.L[I][J] = IN(40 + I * NV + J); }); });
-    S::integrate(f, fs, fc, q, qd);
+    float qacc[NV];
+    static_for<NV>([&](auto I) { qacc[I] = fs[I] + fc[I]; });
+    S::chol_apply(f.L, f.inv, qacc);
+    static_for<NV>([&](auto I) { qd[I] = qd[I] + float(MD::H) * qacc[I]; });
+    S::advance_pos(q, qd, q);
     static_for<NV>([&](auto I) { OUT(I) = q[I]; OUT(NV + I) = qd[I]; });
 }
 __global__ void __launch_bounds__(64) c_substep(const float* in, float* out) {

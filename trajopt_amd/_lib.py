@@ -30,7 +30,7 @@ class ModelDescC(C.Structure):
         ("ctrl_hi", _d * MAXV), ("dof_invweight", _d * MAXV), ("contact_pos", _d * 3),
         ("contact_radius", _d), ("contact_plane_z", _d), ("contact_margin", _d), ("contact_invweight", _d),
         ("hand_pos", _d * 3), ("solref_k", _d), ("solref_b", _d), ("solimp", _d * 5),
-        ("gravity", _d * 3), ("jtype", _i32 * MAXV), ("nq", _i32), ("qadr", _i32 * MAXV),
+        ("gravity", _d * 3), ("jtype", _i32 * MAXV), ("nq", _i32), ("qadr", _i32 * MAXV), ("integrator", _i32),
     ]
 
 
@@ -130,6 +130,7 @@ def desc_to_c(md) -> ModelDescC:
     m.name = md.name.encode()
     m.nv, m.frame_skip, m.h = md.nv, md.frame_skip, md.h
     m.nq = int(md.nq)
+    m.integrator = int(md.integrator)
     m.contact_link, m.hand_link = md.contact_link, md.hand_link
     for i in range(md.nv):
         m.parent[i] = int(md.parent[i]); m.limited[i] = int(md.limited[i]); m.jtype[i] = int(md.jtype[i])

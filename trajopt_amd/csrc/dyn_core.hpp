@@ -380,7 +380,7 @@ template <class T, class MD> struct Step {
     struct DampedFactor { T L[NV][NV], inv[NV]; };       // inv[j] = 1 / L_jj
     static MPPI_HD void factor_damped(const T (&M)[NV][NV], DampedFactor& f) {
         T hb[NV];
-        static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::H * MD::damping[Ic]); });
+        static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::INTEGRATOR == 0 ? MD::H * MD::damping[Ic] : 0.0); });
         chol_factor<false>(M, hb, T(0), hb, f.L, f.inv);
     }
 
@@ -388,7 +388,7 @@ template <class T, class MD> struct Step {
     //   act      : active rows carried from the previous substep; reset() at the start of a rollout.  The
     //              iteration converges to the same unique solution from any start; starting from the
     //              previous set usually needs one sweep.
-    //   damped   : receives the factor of M + h B, which integrate() needs afterwards; it is computed
+    //   damped   : receives the factor of M + h B, which the step needs afterwards; it is computed
     //              inside the first sweep, column by column next to the constraint system's own factor
     //              (two independent chains keep a lone wave's pipeline busy).
     // The loop is uniform over the wave: lanes whose set has settled repeat the same solve (same result)
@@ -425,7 +425,7 @@ template <class T, class MD> struct Step {
                 return changed;
             };
             T hb[NV];
-            static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::H * MD::damping[Ic]); });
+            static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::INTEGRATOR == 0 ? MD::H * MD::damping[Ic] : 0.0); });
             // the sweeps exist twice, with and without the contact row, chosen once per substep: a taken
             // branch costs a lone wave about as much as a dozen vector instructions
             auto sweep_all = [&](auto Wc) {
@@ -468,19 +468,15 @@ template <class T, class MD> struct Step {
         sweeps_out = sweeps;
     }
 
-    // v += h a with (M + h B) a = fs + fc, then q += h v; a ball joint's quaternion is turned by the new angular
-    // velocity (body frame) over h and renormalised
-    static MPPI_HD void integrate(const DampedFactor& f, const T (&fs)[NV], const T (&fc)[NV], T (&q)[NQ], T (&qd)[NV]) {
-        T qacc[NV];
-        static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
-        chol_apply(f.L, f.inv, qacc);
+    // qpos advanced from q0 by h along `vel`: hinge and slide coordinates move linearly, a ball joint's quaternion
+    // is turned by the body-frame rotation vector h w and renormalised.  q may be q0.
+    static MPPI_HD void advance_pos(const T (&q0)[NQ], const T (&vel)[NV], T (&q)[NQ]) {
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             constexpr int a = MD::qadr[i];
-            qd[i] = qd[i] + T(MD::H) * qacc[i];
             if constexpr (MD::jtype[i] == 4) {               // a ball is integrated at its last link, all three rates known
                 constexpr int i0 = i - 2;
-                const T wx = qd[i0], wy = qd[i0 + 1], wz = qd[i0 + 2];
+                const T wx = vel[i0], wy = vel[i0 + 1], wz = vel[i0 + 2];
                 const T n2 = wx * wx + wy * wy + wz * wz;
                 const T n = sqrt_t(n2);
                 const T half_angle = T(0.5 * MD::H) * n;
@@ -488,7 +484,7 @@ template <class T, class MD> struct Step {
                 sincos_t(half_angle, sh, ch);
                 const T g = sel(n2 > T(1e-24), sh * rcp_t(sel(n2 > T(1e-24), n, T(1))), T(0.5 * MD::H));      // sin(h n / 2) / n
                 const T dx = g * wx, dy = g * wy, dz = g * wz;
-                const T qw = q[a], qx = q[a + 1], qy = q[a + 2], qz = q[a + 3];
+                const T qw = q0[a], qx = q0[a + 1], qy = q0[a + 2], qz = q0[a + 3];
                 const T r0 = qw * ch - qx * dx - qy * dy - qz * dz;
                 const T r1 = qw * dx + qx * ch + qy * dz - qz * dy;
                 const T r2 = qw * dy - qx * dz + qy * ch + qz * dx;
@@ -496,16 +492,15 @@ template <class T, class MD> struct Step {
                 const T inv = rsqrt_t(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
                 q[a] = r0 * inv; q[a + 1] = r1 * inv; q[a + 2] = r2 * inv; q[a + 3] = r3 * inv;
             } else if constexpr (!is_ball(i)) {
-                q[a] = q[a] + T(MD::H) * qd[i];
+                q[a] = q0[a] + T(MD::H) * vel[i];
             }
         });
     }
 
-    // (q, v, ctrl) -> (q', v') in place.
-    //   want_hand : also evaluate the end-effector site at the input q
-    //   act       : see constraint_forces
-    static MPPI_HD void substep(T (&q)[NQ], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
-                                Active& act, int& sweeps_out) {
+    // joint acceleration at (q, v, ctrl): the factor's matrix is M + h B for the Euler step (joint damping
+    // implicit) and M alone for Runge-Kutta stages
+    static MPPI_HD void acceleration(const T (&q)[NQ], const T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
+                                     Active& act, int& sweeps_out, T (&qacc)[NV]) {
         Frames fr;
         frames(q, fr);
         if constexpr (MD::hand_link >= 0) {
@@ -520,7 +515,56 @@ template <class T, class MD> struct Step {
         DampedFactor f;
         T fc[NV];
         constraint_forces(M, fs, rows, act, fc, sweeps_out, f);
-        integrate(f, fs, fc, q, qd);
+        static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
+        chol_apply(f.L, f.inv, qacc);
+    }
+
+    // (q, v, ctrl) -> (q', v') in place.
+    //   want_hand : also evaluate the end-effector site at the configuration the simulator's derived quantities
+    //               hold after the step: the last one its dynamics were evaluated at (Euler: the input q;
+    //               Runge-Kutta: the fourth stage)
+    //   act       : see constraint_forces
+    static MPPI_HD void substep(T (&q)[NQ], T (&qd)[NV], const T (&ctrl)[NV], bool want_hand, Out& out,
+                                Active& act, int& sweeps_out) {
+        if constexpr (MD::INTEGRATOR == 0) {
+            // semi-implicit Euler: v += h a with (M + h B) a = fs + fc, then q advanced along the new v
+            T qacc[NV];
+            acceleration(q, qd, ctrl, want_hand, out, act, sweeps_out, qacc);
+            static_for<NV>([&](auto Ic) { qd[Ic] = qd[Ic] + T(MD::H) * qacc[Ic]; });
+            advance_pos(q, qd, q);
+        } else {
+            // classical fourth-order Runge-Kutta over (qpos, qvel): stage states X_s = X_0 + h a_s (v_{s-1}, F_{s-1})
+            // with a = (1/2, 1/2, 1), positions advanced on the manifold; result X_0 + h sum_s b_s (v_s, F_s),
+            // b = (1, 2, 2, 1) / 6.  The four stages run through one copy of the dynamics code.
+            T q0[NQ], v0[NV], dvel[NV], dacc[NV];
+            static_for<NQ>([&](auto Ic) { q0[Ic] = q[Ic]; });
+            static_for<NV>([&](auto Ic) { v0[Ic] = qd[Ic]; dvel[Ic] = T(0); dacc[Ic] = T(0); });
+            int sweeps = 0;
+#if defined(__clang__)
+#pragma nounroll
+#endif
+            for (int s = 0; s < 4; s++) {
+                T F[NV];
+                int sw;
+                acceleration(q, qd, ctrl, want_hand && s == 3, out, act, sw, F);
+                sweeps = sw > sweeps ? sw : sweeps;
+                const T b = (s == 0 || s == 3) ? T(1.0 / 6.0) : T(1.0 / 3.0);
+                const T a = (s == 2) ? T(1) : T(0.5);          // coefficient of the stage that follows
+                T va[NV];
+                static_for<NV>([&](auto Ic) {
+                    dvel[Ic] += b * qd[Ic];
+                    dacc[Ic] += b * F[Ic];
+                    va[Ic] = a * qd[Ic];
+                });
+                if (s < 3) {
+                    advance_pos(q0, va, q);
+                    static_for<NV>([&](auto Ic) { qd[Ic] = v0[Ic] + T(MD::H) * a * F[Ic]; });
+                }
+            }
+            static_for<NV>([&](auto Ic) { qd[Ic] = v0[Ic] + T(MD::H) * dacc[Ic]; });
+            advance_pos(q0, dvel, q);
+            sweeps_out = sweeps;
+        }
     }
 
     // bias forces: recursive Newton-Euler with zero joint acceleration, link-local coordinates.

@@ -682,6 +682,7 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
     if (!(cond)) { why = std::string("model field differs from the compiled kernel: ") + what; return false; }
     CHK(d->nv == NV, "nv");
     CHK(d->nq == MD::NQ, "nq");
+    CHK(d->integrator == MD::INTEGRATOR, "integrator");
     CHK(d->frame_skip == MD::FRAME_SKIP, "frame_skip");
     CHK(near(d->h, MD::H), "timestep");
     CHK(d->contact_link == MD::contact_link, "contact_link");
@@ -832,7 +833,8 @@ template <class MD> static ModelOps make_ops() {
 #if defined(MPPI_ONLY_REACHER)      // quick builds for kernel experiments (make quick / make quickasm)
 static const ModelOps g_ops[] = {make_ops<Reacher7Dof>()};
 #else
-static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>(), make_ops<Tree18DofQuat>()};
+static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>(), make_ops<Tree18DofQuat>(),
+                                 make_ops<Tree18DofRk4>()};
 #endif
 
 // ------------------------------------------------------------------------------------------

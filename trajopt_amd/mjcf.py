@@ -4,7 +4,7 @@ The reference passes its XML asset to the simulator (`trajopt/envs/mujoco_env.py
 `trajopt/envs/assets/sawyer.xml`); this reads the subset of that format the compiler understands:
 
     <compiler angle="radian" coordinate="local" inertiafromgeom="true"/>
-    <option timestep gravity integrator="Euler"/>
+    <option timestep gravity integrator="Euler|RK4"/>
     <default> <joint .../> <geom .../> <motor .../> </default>      (top-level defaults only)
     <worldbody> nested <body pos> with <joint type="hinge|slide|ball|free" axis range damping armature limited>
                 or <freejoint/> (free: position + unit quaternion in qpos, world-frame linear and body-frame
@@ -13,7 +13,7 @@ The reference passes its XML asset to the simulator (`trajopt/envs/mujoco_env.py
     <actuator> <motor joint gear ctrlrange/> </actuator>
 
 Anything else that would change the dynamics (body orientations, joint offsets, other geom or joint
-types, tendons, equality constraints, non-Euler integrators) raises `ValueError`; purely visual
+types, tendons, equality constraints, implicit integrators) raises `ValueError`; purely visual
 elements and attributes are ignored.
 """
 import xml.etree.ElementTree as ET
@@ -53,8 +53,9 @@ def load_mjcf(source, name, frame_skip, hand_site="finger") -> ModelSpec:
         raise ValueError("a <compiler angle=\"radian\"> element is required (the format's default is degrees)")
     opt = root.find("option")
     oa = {} if opt is None else opt.attrib
-    if oa.get("integrator", "Euler") != "Euler":
-        raise ValueError("integrator %r has no kernel (Euler only)" % oa.get("integrator"))
+    integrator = oa.get("integrator", "Euler")
+    if integrator not in ("Euler", "RK4"):
+        raise ValueError("integrator %r has no kernel (Euler and RK4 only)" % integrator)
     timestep = float(oa.get("timestep", 0.002))
     gravity = _floats(oa.get("gravity", "0 0 -9.81"), 3)
 
@@ -173,4 +174,5 @@ def load_mjcf(source, name, frame_skip, hand_site="finger") -> ModelSpec:
     kw = {}
     if opt is not None and "o_solref" in oa:
         kw["solref"] = _floats(oa["o_solref"], 2)
-    return ModelSpec(name, timestep, frame_skip, roots, plane_z=plane_z[0], gravity=gravity, hand_site=hand_site, **kw)
+    return ModelSpec(name, timestep, frame_skip, roots, plane_z=plane_z[0], gravity=gravity, hand_site=hand_site,
+                     integrator=integrator, **kw)

@@ -76,6 +76,7 @@ class ModelSpec:
     solimp: Tuple[float, float, float, float, float] = (0.9, 0.95, 0.001, 0.5, 2.0)
     gravity: Tuple[float, float, float] = (0.0, 0.0, 0.0)
     hand_site: str = "finger"
+    integrator: str = "Euler"                           # 'Euler' (joint damping implicit) | 'RK4'
 
 
 def reacher_7dof_spec() -> ModelSpec:
@@ -154,6 +155,16 @@ def tree_18dof_quat_spec() -> ModelSpec:
     s.name = "tree_18dof_quat"
     trunk = s.root[0]
     trunk.joints = [Joint((0, 0, 1), kind="free", damping=0.0, armature=0.0, gear=0.0, limited=False, range=(0.0, 0.0))]
+    return s
+
+
+def tree_18dof_rk4_spec() -> ModelSpec:
+    """`tree_18dof_quat` stepped with the fourth-order Runge-Kutta integrator (the integrator of the
+    reference's `trajopt/envs/assets/hopper.xml:8`) at twice the time step."""
+    s = tree_18dof_quat_spec()
+    s.name = "tree_18dof_rk4"
+    s.integrator = "RK4"
+    s.timestep = 0.01
     return s
 
 
@@ -251,6 +262,7 @@ class ModelDesc:
     gravity: np.ndarray = None  # (3,)
     nq: int = None            # length of qpos: nv + number of ball joints
     qadr: np.ndarray = None   # (nv,) int32: qpos index of the joint's coordinate (a ball's three links: its quaternion w)
+    integrator: int = 0       # 0 semi-implicit Euler with implicit joint damping, 1 fourth-order Runge-Kutta
 
     def __post_init__(self):
         if self.jtype is None:
@@ -412,7 +424,8 @@ def compile_model(spec: ModelSpec) -> ModelDesc:
         solimp=np.asarray(spec.solimp, float),
         jtype=np.array([dict(hinge=HINGE, slide=SLIDE, ball_x=BALL_X, ball_y=BALL_Y, ball_z=BALL_Z)[l["joint"].kind]
                         for l in links], np.int32),
-        gravity=np.asarray(spec.gravity, float))
+        gravity=np.asarray(spec.gravity, float),
+        integrator={"Euler": 0, "RK4": 1}[spec.integrator])
     contact_body = None
     for i, l in enumerate(links):
         j = l["joint"]
@@ -487,6 +500,8 @@ def get_model(name: str) -> ModelDesc:
             _CACHE[name] = compile_model(tree_18dof_spec())
         elif name == "tree_18dof_quat":
             _CACHE[name] = compile_model(tree_18dof_quat_spec())
+        elif name == "tree_18dof_rk4":
+            _CACHE[name] = compile_model(tree_18dof_rk4_spec())
         else:
             raise KeyError(name)
     return _CACHE[name]

@@ -42,12 +42,13 @@ def cpu_baseline(cores):
     md = get_model("reacher_7dof")
     start = dict(qp=np.zeros(M), qv=np.zeros(M), target_pos=np.zeros(3), timestep=0)
     ppc = K_PER_GPU // cores
-    iters = 2
-    t0 = time.perf_counter()
+    iters = 3
+    times = []
     for i in range(iters):
+        t0 = time.perf_counter()
         ref_rollout.planning_iteration(md, start, np.zeros((H, M)), FILTER, SEED + i, KAPPA, GAMMA, ppc, cores)
-    dt = time.perf_counter() - t0
-    py = iters * ppc * cores * H / dt
+        times.append(time.perf_counter() - t0)
+    py = ppc * cores * H / sorted(times)[iters // 2]          # median of the repeats
     # the same arithmetic without the Python loop: multithreaded C++ rollouts
     from oracle import ref_mppi
     act = ref_mppi.filter_noise(ref_mppi.raw_normals(SEED, 2048, H, M), FILTER)
@@ -56,7 +57,7 @@ def cpu_baseline(cores):
     sim.rollout(np.zeros(M), np.zeros(M), np.zeros(3), 0, act, nthreads=cores)
     c_rate = 2048 * H / (time.perf_counter() - t0)
     return {"value": py, "unit": "env_steps/s", "cores": cores, "kind": "port",
-            "sample": "%d planning iterations of gather_paths_parallel + update at K=%d (=%d workers x %d paths), H=%d, "
+            "sample": "median of %d planning iterations of gather_paths_parallel + update at K=%d (=%d workers x %d paths), H=%d, "
                       "Python-structured restatement of the reference path on the fp64 C++ simulator restatement "
                       "(MuJoCo is not installed)" % (iters, ppc * cores, cores, ppc, H),
             "c_rollouts_only_env_steps_per_s": c_rate}

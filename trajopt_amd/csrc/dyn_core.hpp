@@ -222,6 +222,21 @@ template <class T, class MD> struct Step {
         return false;
     }
 
+    // M[i][j] can be nonzero only between a link and its ancestors
+    static constexpr bool coupled(int i, int j) { return i >= j ? on_path(j, i) : on_path(i, j); }
+    static constexpr bool branching() {
+        for (int i = 0; i < NV; i++) if (MD::parent[i] != i - 1) return true;
+        return false;
+    }
+    static constexpr bool has_rows() {
+        if (MD::contact_link >= 0) return true;
+        for (int i = 0; i < NV; i++) if (MD::limited[i] != 0) return true;
+        return false;
+    }
+    // Branching models without constraint rows factor M + h B from the leaves towards the root (below): no
+    // fill-in between branches.  Models with rows keep the root-first order their constraint solve shares.
+    static constexpr bool LEAF_FIRST = branching() && !has_rows();
+
     // coordinates of a point fixed in link I, expressed in every ancestor frame on the way to the
     // world: x[i] = point in link-i coordinates, returns world coordinates
     template <int I>
@@ -381,7 +396,8 @@ template <class T, class MD> struct Step {
     static MPPI_HD void factor_damped(const T (&M)[NV][NV], DampedFactor& f) {
         T hb[NV];
         static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::INTEGRATOR == 0 ? MD::H * MD::damping[Ic] : 0.0); });
-        chol_factor<false>(M, hb, T(0), hb, f.L, f.inv);
+        if constexpr (LEAF_FIRST) leaf_first_factor(M, hb, f.L, f.inv);
+        else chol_factor<false>(M, hb, T(0), hb, f.L, f.inv);
     }
 
     // exact active-set solve of the soft constraint rows: fc = J^T f with f >= 0 on the active rows.
@@ -516,7 +532,8 @@ template <class T, class MD> struct Step {
         T fc[NV];
         constraint_forces(M, fs, rows, act, fc, sweeps_out, f);
         static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
-        chol_apply(f.L, f.inv, qacc);
+        if constexpr (LEAF_FIRST) leaf_first_apply(f.L, f.inv, qacc);
+        else chol_apply(f.L, f.inv, qacc);
     }
 
     // (q, v, ctrl) -> (q', v') in place.
@@ -844,6 +861,62 @@ template <class T, class MD> struct Step {
             sched_fence();
         });
         back_substitute(L, inv, b);
+    }
+
+    // ---- branch-aware solver ---------------------------------------------------------------------------
+    // A = M + diag(dg) = L^T L with L lower triangular, eliminated from the last link to the first.  A link
+    // couples only to its ancestors, and two ancestors of one link are ancestors of each other, so eliminating
+    // leaves first creates no fill-in: L has the zero pattern of M, and limbs of a tree never meet in the
+    // factor (root-first Cholesky of the same matrix fills every limb-limb block).  Row k of L is stored in
+    // L[k][i], i < k; inv[k] = 1 / L_kk.
+    static MPPI_HD void leaf_first_factor(const T (&M)[NV][NV], const T (&dg)[NV], T (&L)[NV][NV], T (&inv)[NV]) {
+        static_for<NV>([&](auto In) {
+            constexpr int i = In;
+            static_for<i + 1>([&](auto Jn) {
+                constexpr int j = Jn;
+                if constexpr (i == j) L[i][j] = M[i][j] + dg[i];
+                else if constexpr (coupled(i, j)) L[i][j] = M[i][j];
+            });
+        });
+        static_for<NV>([&](auto Kn) {
+            constexpr int k = NV - 1 - Kn;
+            inv[k] = rsqrt_t(L[k][k]);
+            static_for<k>([&](auto In) {
+                constexpr int i = In;
+                if constexpr (coupled(k, i)) L[k][i] *= inv[k];
+            });
+            static_for<k>([&](auto In) {
+                constexpr int i = In;
+                if constexpr (coupled(k, i)) {
+                    static_for<i + 1>([&](auto Jn) {
+                        constexpr int j = Jn;
+                        if constexpr (coupled(k, j)) L[i][j] -= L[k][i] * L[k][j];
+                    });
+                }
+            });
+        });
+    }
+    // b <- (L^T L)^-1 b
+    static MPPI_HD void leaf_first_apply(const T (&L)[NV][NV], const T (&inv)[NV], T (&b)[NV]) {
+        // L^T y = b, from the last link down
+        static_for<NV>([&](auto Kn) {
+            constexpr int k = NV - 1 - Kn;
+            b[k] *= inv[k];
+            static_for<k>([&](auto In) {
+                constexpr int i = In;
+                if constexpr (coupled(k, i)) b[i] -= L[k][i] * b[k];
+            });
+        });
+        // L x = y, from the root up
+        static_for<NV>([&](auto Kn) {
+            constexpr int k = Kn;
+            T acc = b[k];
+            static_for<k>([&](auto In) {
+                constexpr int i = In;
+                if constexpr (coupled(k, i)) acc -= L[k][i] * b[i];
+            });
+            b[k] = acc * inv[k];
+        });
     }
 };
 

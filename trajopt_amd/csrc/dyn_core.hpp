@@ -116,6 +116,26 @@ template <> struct PairOf<float> { typedef float type __attribute__((vector_size
 template <> struct PairOf<double> { typedef double type __attribute__((vector_size(16))); };
 template <class T> using Pair = typename PairOf<T>::type;
 template <class T> MPPI_HD Pair<T> make_pair_of(T a, T b) { Pair<T> p = {a, b}; return p; }
+// a pair of which only half H is ever looked at (the other half costs no instruction on the device)
+template <int H, class T> MPPI_HD Pair<T> half_pair(T a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Pair<T> p;
+    p[H] = a;
+    return p;
+#else
+    Pair<T> p = {a, a};
+    return p;
+#endif
+}
+// both halves set to half H of a pair
+template <int H, class P> MPPI_HD P splat_half(const P& a) {
+#if defined(__clang__)
+    return __builtin_shufflevector(a, a, H, H);
+#else
+    P r = {a[H], a[H]};
+    return r;
+#endif
+}
 template <class T> MPPI_HD Vec3<T> half(const Vec3<Pair<T>>& a, int h) { return {{a.v[0][h], a.v[1][h], a.v[2][h]}}; }
 
 // a x b for any mix of scalar and paired operands
@@ -811,7 +831,9 @@ template <class T, class MD> struct Step {
                         return a;
                     }
                 };
-                A.col[j][p] = make_pair_of(entry(std::integral_constant<int, 2 * p>{}), entry(std::integral_constant<int, 2 * p + 1>{}));
+                if constexpr (2 * p < j) A.col[j][p] = half_pair<1>(entry(std::integral_constant<int, 2 * p + 1>{}));
+                else if constexpr (2 * p + 1 >= NV) A.col[j][p] = half_pair<0>(entry(std::integral_constant<int, 2 * p>{}));
+                else A.col[j][p] = make_pair_of(entry(std::integral_constant<int, 2 * p>{}), entry(std::integral_constant<int, 2 * p + 1>{}));
             });
         });
     }
@@ -822,7 +844,7 @@ template <class T, class MD> struct Step {
         static_for<NP - (j + 1) / 2>([&](auto Pn) { constexpr int p = (j + 1) / 2 + Pn; A.col[j][p] *= inv[j]; });
         static_for<NV - 1 - j>([&](auto Kn) {
             constexpr int k = j + 1 + Kn;
-            const T m = A.col[j][k / 2][k % 2];
+            const Pair<T> m = splat_half<k % 2>(A.col[j][k / 2]);
             static_for<NP - k / 2>([&](auto Pn) { constexpr int p = k / 2 + Pn; A.col[k][p] -= A.col[j][p] * m; });
         });
     }
@@ -831,7 +853,7 @@ template <class T, class MD> struct Step {
         static_for<NP>([&](auto Pn) {
             constexpr int p = Pn;
             if constexpr (2 * p + 1 < NV) bp[p] = make_pair_of(b[2 * p], b[2 * p + 1]);
-            else bp[p] = make_pair_of(b[2 * p], T(0));
+            else bp[p] = half_pair<0>(b[2 * p]);
         });
     }
     // forward substitution step j: y_j is final, later rows accumulate

@@ -58,21 +58,21 @@ __global__ void __launch_bounds__(64) c_chol_solve(const float* in, float* out) 
     S::chol_solve<false>(A, dg, 0.f, dg, b);
     static_for<NV>([&](auto I) { OUT(I) = b[I]; });
 }
-__global__ void __launch_bounds__(64) c_chol_solve_and_factor(const float* in, float* out) {
+__global__ void __launch_bounds__(64) c_dual_factor(const float* in, float* out) {
     float A[NV][NV], b[NV], dg[NV], d2[NV];
     static_for<NV>([&](auto I) { b[I] = IN(49 + I); dg[I] = IN(60 + I); d2[I] = IN(70 + I); static_for<I + 1>([&](auto J) { A[I][J] = IN(I * NV + J); }); });
     typename S::DampedFactor f;
-    S::chol_solve_and_factor<false>(A, dg, 0.f, dg, b, d2, f.P, f.inv);
-    static_for<NV>([&](auto I) { OUT(I) = b[I]; OUT(NV + I) = f.inv[I]; static_for<S::NP - I / 2>([&](auto Pn) { OUT(20 + 2 * (I * S::NP + I / 2 + Pn)) = f.P.col[I][I / 2 + Pn][0]; OUT(21 + 2 * (I * S::NP + I / 2 + Pn)) = f.P.col[I][I / 2 + Pn][1]; }); });
+    S::dual_factor<false, true>(A, dg, 0.f, dg, b, d2, f.D, f.inv);
+    static_for<NV>([&](auto I) { OUT(I) = b[I]; OUT(NV + I) = f.inv[I]; static_for<I>([&](auto J) { OUT(20 + I * NV + J) = f.D.a[I][J][1]; }); });
 }
 __global__ void __launch_bounds__(64) c_integrate(const float* in, float* out) {
     typename S::DampedFactor f;
     float fs[NV], fc[NV], q[NV], qd[NV];
     static_for<NV>([&](auto I) { fs[I] = IN(I); fc[I] = IN(NV + I); q[I] = IN(2 * NV + I); qd[I] = IN(3 * NV + I); f.inv[I] = IN(4 * NV + I);
-                                 static_for<S::NP - I / 2>([&](auto Pn) { f.P.col[I][I / 2 + Pn] = make_pair_of(IN(40 + 2 * (I * S::NP + Pn)), IN(41 + 2 * (I * S::NP + Pn))); }); });
+                                 static_for<I>([&](auto J) { f.D.a[I][J] = half_pair<1>(IN(40 + I * NV + J)); }); });
     float qacc[NV];
     static_for<NV>([&](auto I) { qacc[I] = fs[I] + fc[I]; });
-    S::chol_apply(f.P, f.inv, qacc);
+    S::dual_apply(f.D, f.inv, qacc);
     static_for<NV>([&](auto I) { qd[I] = qd[I] + float(MD::H) * qacc[I]; });
     S::advance_pos(q, qd, q);
     static_for<NV>([&](auto I) { OUT(I) = q[I]; OUT(NV + I) = qd[I]; });

@@ -415,7 +415,12 @@ template <class T, class MD> struct Step {
     // a lower-triangular matrix held as pairs of rows (see the dense solver below)
     static constexpr int NP = (NV + 1) / 2;
     struct PackedSystem { Pair<T> col[NV][NP]; };      // col[j][p] = rows {2p, 2p+1} of column j, 2p+1 >= j
+    // two lower-triangular matrices held entry by entry side by side (see the dense solver below)
+    struct DualSystem { Pair<T> a[NV][NV]; };
+    // Models with constraint rows factor M + h B next to the first sweep's system, entry by entry in pairs.
+    static constexpr bool DUAL = has_rows() && !LEAF_FIRST;
     struct DampedFactor {                                // inv[j] = 1 / L_jj
+        DualSystem D;        // half [1]: root-first factor, made next to the constraint system's
         PackedSystem P;      // root-first factor (row pairs)
         T L[NV][NV];         // leaf-first factor of a branching model
         T inv[NV];
@@ -424,7 +429,12 @@ template <class T, class MD> struct Step {
         T hb[NV];
         static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::INTEGRATOR == 0 ? MD::H * MD::damping[Ic] : 0.0); });
         if constexpr (LEAF_FIRST) leaf_first_factor(M, hb, f.L, f.inv);
-        else chol_factor<false>(M, hb, T(0), hb, f.P, f.inv);
+        else if constexpr (DUAL) {
+            // no row in the whole wave (rare for a model that has rows): the same routine, its first system idle
+            T none[NV], unused[NV];
+            static_for<NV>([&](auto Ic) { none[Ic] = T(0); unused[Ic] = T(0); });
+            dual_factor<false, false>(M, none, T(0), none, unused, hb, f.D, f.inv);
+        } else chol_factor<false>(M, hb, T(0), hb, f.P, f.inv);
     }
 
     // exact active-set solve of the soft constraint rows: fc = J^T f with f >= 0 on the active rows.
@@ -432,8 +442,8 @@ template <class T, class MD> struct Step {
     //              iteration converges to the same unique solution from any start; starting from the
     //              previous set usually needs one sweep.
     //   damped   : receives the factor of M + h B, which the step needs afterwards; it is computed
-    //              inside the first sweep, column by column next to the constraint system's own factor
-    //              (two independent chains keep a lone wave's pipeline busy).
+    //              inside the first sweep, entry by entry next to the constraint system's own factor
+    //              (one packed instruction serves both).
     // The loop is uniform over the wave: lanes whose set has settled repeat the same solve (same result)
     // until every lane has settled, so the only cross-lane operation is one vote per sweep.
     static MPPI_HD void constraint_forces(const T (&M)[NV][NV], const T (&fs)[NV], const Rows& r, Active& act,
@@ -479,7 +489,8 @@ template <class T, class MD> struct Step {
                 };
                 sweeps = 1;
                 right_hand_side();
-                chol_solve_and_factor<WC>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.P, damped.inv);
+                // (a model without rows never gets here: its rows.any is false at compile time)
+                if constexpr (DUAL) dual_factor<WC, true>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.D, damped.inv);
                 Mask<T> changed = settle();
                 // a set carried over from the previous substep is usually confirmed by the first sweep
                 if (MPPI_UNLIKELY(wave_any(changed))) {
@@ -560,6 +571,7 @@ template <class T, class MD> struct Step {
         constraint_forces(M, fs, rows, act, fc, sweeps_out, f);
         static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
         if constexpr (LEAF_FIRST) leaf_first_apply(f.L, f.inv, qacc);
+        else if constexpr (DUAL) dual_apply(f.D, f.inv, qacc);
         else chol_apply(f.P, f.inv, qacc);
     }
 
@@ -900,25 +912,61 @@ template <class T, class MD> struct Step {
         });
         back_substitute(L, inv, b);
     }
-    // chol_solve for system 1 = M + diag(dg) + dc * Jc Jc^T with right-hand side b and, column by column
-    // next to it, the factor (L2, inv2) of system 2 = M + diag(d2): two independent chains of dependent
-    // instructions, which a lone wave issues faster than one after the other
-    template <bool CONTACT>
-    static MPPI_HD void chol_solve_and_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&b)[NV],
-                                              const T (&d2)[NV], PackedSystem& L2, T (&inv2)[NV]) {
-        PackedSystem L;
-        T inv[NV];
-        Pair<T> bp[NP];
-        build_system<CONTACT>(M, dg, dc, Jc, L);
-        build_system<false>(M, d2, T(0), Jc, L2);
-        pack_rhs(b, bp);
+    // ---- two systems at once ---------------------------------------------------------------------------
+    // System 1 = M + diag(dg) + dc * Jc Jc^T with right-hand side b (SOLVE: b becomes the solution) and
+    // system 2 = M + diag(d2), factored in the same right-looking order with every entry of the two held as one
+    // pair: scaling and updates are one packed instruction for both systems, with no idle halves.  Half [1]
+    // of A and inv2 are the factor of system 2 afterwards.
+    template <bool CONTACT, bool SOLVE>
+    static MPPI_HD void dual_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], T (&b)[NV],
+                                    const T (&d2)[NV], DualSystem& A, T (&inv2)[NV]) {
+        static_for<NV>([&](auto In) {
+            constexpr int i = In;
+            static_for<i + 1>([&](auto Jn) {
+                constexpr int j = Jn;
+                T a1 = M[i][j], a2 = M[i][j];
+                if constexpr (i == j) { a1 += dg[i]; a2 += d2[i]; }
+                if constexpr (CONTACT) a1 += dc * Jc[i] * Jc[j];
+                A.a[i][j] = make_pair_of(a1, a2);
+            });
+        });
+        T inv1[NV];
         static_for<NV>([&](auto Jn) {
-            eliminate_column<Jn>(L, inv);
-            eliminate_column<Jn>(L2, inv2);
-            forward_column<Jn>(L, inv, bp, b);
+            constexpr int j = Jn;
+            inv1[j] = rsqrt_t(A.a[j][j][0]);
+            inv2[j] = rsqrt_t(A.a[j][j][1]);
+            const Pair<T> ip = make_pair_of(inv1[j], inv2[j]);
+            static_for<NV - 1 - j>([&](auto In) { A.a[j + 1 + In][j] *= ip; });
+            static_for<NV - 1 - j>([&](auto Kn) {
+                constexpr int k = j + 1 + Kn;
+                static_for<NV - k>([&](auto In) { constexpr int i = k + In; A.a[i][k] -= A.a[i][j] * A.a[k][j]; });
+            });
+            if constexpr (SOLVE) {
+                b[j] *= inv1[j];
+                static_for<NV - 1 - j>([&](auto In) { constexpr int i = j + 1 + In; b[i] -= A.a[i][j][0] * b[j]; });
+            }
             sched_fence();
         });
-        back_substitute(L, inv, b);
+        if constexpr (SOLVE) {
+            static_for<NV>([&](auto Kn) {
+                constexpr int k = NV - 1 - Kn;
+                b[k] *= inv1[k];
+                static_for<k>([&](auto In) { constexpr int i = k - 1 - In; b[i] -= A.a[k][i][0] * b[k]; });
+            });
+        }
+    }
+    // b <- (L L^T)^-1 b with the factor of system 2
+    static MPPI_HD void dual_apply(const DualSystem& A, const T (&inv)[NV], T (&b)[NV]) {
+        static_for<NV>([&](auto Jn) {
+            constexpr int j = Jn;
+            b[j] *= inv[j];
+            static_for<NV - 1 - j>([&](auto In) { constexpr int i = j + 1 + In; b[i] -= A.a[i][j][1] * b[j]; });
+        });
+        static_for<NV>([&](auto Kn) {
+            constexpr int k = NV - 1 - Kn;
+            b[k] *= inv[k];
+            static_for<k>([&](auto In) { constexpr int i = k - 1 - In; b[i] -= A.a[k][i][1] * b[k]; });
+        });
     }
 
     // ---- branch-aware solver ---------------------------------------------------------------------------

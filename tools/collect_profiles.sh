@@ -19,7 +19,7 @@ echo "kernel trace done"
 
 # counters: one pass each, nothing else traced
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
-    SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$O/pmc_sq" -- python3 "$R/tools/ksweep.py" 4096 > "$O/pmc_sq.log" 2>&1
+    SQ_WAIT_ANY SQ_INSTS_BRANCH --output-format csv -d "$O/pmc_sq" -- python3 "$R/tools/ksweep.py" 4096 > "$O/pmc_sq.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/tools/ksweep.py" 4096 > "$O/pmc_fetch.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/tools/ksweep.py" 4096 > "$O/pmc_write.log" 2>&1
 python3 "$R/tools/summarize_pmc.py" sq "$O/pmc_sq" > "$O/rollout_pmc_sq.json"
@@ -33,5 +33,6 @@ timeout -k 10 180 python3 "$R/tools/bench_planners.py" > "$O/planners.jsonl" 2> 
 timeout -k 10 180 python3 "$R/tools/time_train_step.py" > "$O/train_step.jsonl" 2> /dev/null
 timeout -k 10 240 python3 "$R/tools/tree_study.py" "$O/tree_quat_study.json" tree_18dof_quat > /dev/null 2> "$O/tree_quat.err"
 timeout -k 10 240 python3 "$R/tools/tree_study.py" "$O/tree_study.json" tree_18dof > /dev/null 2> "$O/tree.err"
+timeout -k 10 240 python3 "$R/tools/tree_study.py" "$O/tree_rk4_study.json" tree_18dof_rk4 > /dev/null 2> "$O/tree_rk4.err"
 rm -rf "$O/trace" "$O/pmc_sq" "$O/pmc_fetch" "$O/pmc_write"
 echo "all done"

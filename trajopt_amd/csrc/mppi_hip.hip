@@ -2,13 +2,15 @@
 //
 // Kernels (one lane = one sampled action sequence; wave = 64 samples):
 //   noise_upload_kernel / noise_philox_kernel   sigma scaling + recursive 3-tap filter, writes eps[t][j][k]
-//   rollout_kernel<T, MD>                       H env steps x FRAME_SKIP substeps, fused reward + discounted return
-//   weights_kernel<T>                           max / arg-max over K, S_k = exp(kappa (R_k - Rmax)), sum S
-//   wsum_kernel<T>                              sum_k S_k eps[t][j][k] for every (t, j)
-//   update_rows_kernel<T, NV>                   single-rank update in one launch (weights + sums + act_sequence)
+//   rollout_kernel<T, MD, LEAN>                 H env steps x FRAME_SKIP substeps, fused reward + discounted return
+//   update_rows_kernel<T, NV, ROWS>             max / arg-max over K, S_k = exp(kappa (R_k - Rmax)), sum S, sum S eps:
+//                                               the whole update of a single rank, or a shard's statistics
 //   merge_kernel                                rank-ordered merge of shard statistics, writes act_sequence
+//   advance_kernel / advance_noise_kernel       fp64 step of the real environment, log, receding-horizon shift
+//                                               (+ the next step's Philox noise on the other blocks)
 //   shift_kernel                                receding-horizon shift + tail fill
 //   env_step_kernel<MD>                         one fp64 env.step for the real environment
+//   critic_kernel                               terminal value of the 128-wide tanh MLP
 //
 // Layout in HBM: eps is stored step-major, sample-minor ([H][M][K]) so that the 64 lanes of
 // a wave read 64 consecutive values per (t, j); returns are [K]; act_sequence is [H][M] fp64.
@@ -454,75 +456,16 @@ __device__ __forceinline__ void argmax_combine(double& v, int& i, double ov, int
 }
 __device__ __forceinline__ double shfl_xor_d(double x, int m) { return __shfl_xor(x, m, 64); }
 
-// single block: Rmax / first arg-max over K, S[k], sum S  -> part[0..2]
-template <class T>
-__global__ void __launch_bounds__(1024) weights_kernel(const T* __restrict__ R, int K, int HM, double kappa, int k_offset,
-                                                       double* __restrict__ S, double* __restrict__ part) {
-    R += (size_t)blockIdx.x * K; S += (size_t)blockIdx.x * K; part += (size_t)blockIdx.x * (3 + HM);   // one block per planner
-    __shared__ double s_v[16];
-    __shared__ int s_i[16];
-    __shared__ double s_bcast;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double bv = -DBL_MAX;
-    int bi = INT_MAX;
-    for (int k = tid; k < K; k += 1024) argmax_combine(bv, bi, (double)R[k], k);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = shfl_xor_d(bv, m);
-        const int oi = __shfl_xor(bi, m, 64);
-        argmax_combine(bv, bi, ov, oi);
-    }
-    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
-    __syncthreads();
-    bv = s_v[0]; bi = s_i[0];
-    for (int w = 1; w < 16; w++) argmax_combine(bv, bi, s_v[w], s_i[w]);
-    __syncthreads();
-    double den = 0.0;
-    for (int k = tid; k < K; k += 1024) {
-        const double s = exp(kappa * ((double)R[k] - bv));
-        S[k] = s;
-        den += s;
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) den += shfl_xor_d(den, m);
-    if (lane == 0) s_v[wave] = den;
-    __syncthreads();
-    if (tid == 0) {
-        double d = 0.0;
-        for (int w = 0; w < 16; w++) d += s_v[w];
-        part[0] = bv;
-        part[1] = (double)(k_offset + bi);
-        part[2] = d;
-    }
-}
-
-// block hm: num[hm] = sum_k S[k] * eps[hm][k]
-template <class T>
-__global__ void __launch_bounds__(256) wsum_kernel(const double* __restrict__ S, const T* __restrict__ eps, int K,
-                                                   double* __restrict__ part) {
-    __shared__ double s_v[4];
-    const int hm = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int HM = gridDim.x;
-    S += (size_t)blockIdx.y * K; eps += (size_t)blockIdx.y * HM * K; part += (size_t)blockIdx.y * (3 + HM);
-    const T* e = eps + (size_t)hm * K;
-    double num = 0.0;
-    for (int k = tid; k < K; k += 256) num += S[k] * (double)e[k];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) num += shfl_xor_d(num, m);
-    if (lane == 0) s_v[wave] = num;
-    __syncthreads();
-    if (tid == 0) part[3 + hm] = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3];
-}
-
-// Single-rank update in one launch.  A block owns ROWS consecutive (step, action dimension) rows of one planner:
+// Update in one launch (write_base = 1), or one shard's statistics (Rmax, arg-max, sum S, sum S eps) for the
+// exchange between ranks (write_base = 0: act_sequence is left to the merge).  A block owns ROWS consecutive (step, action dimension) rows of one planner:
 // it finds Rmax / first arg-max itself (every block gets the same values, in the same fixed order), evaluates
 // every weight S_k = exp(kappa (R_k - Rmax)) once and accumulates sum S and its ROWS weighted sums, then writes
 // its entries of act_sequence.  ROWS = NV (one block per step) when there are many planners to fill the GPU,
 // ROWS = 1 (one block per entry) for a single planner.  Any block size that is a multiple of 64 up to 1024.
 template <class T, int NV, int ROWS>
 __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
-                                                           int k_offset, int HM, double* __restrict__ base, double* __restrict__ part,
-                                                           double* __restrict__ result) {
+                                                           int k_offset, int HM, int write_base, double* __restrict__ base,
+                                                           double* __restrict__ part, double* __restrict__ result) {
     __shared__ double s_v[16][ROWS + 1];
     __shared__ int s_i[16];
     const int row0 = blockIdx.x * ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -568,12 +511,12 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     const double d = s_v[0][ROWS];
     if (tid < ROWS) {
         const double n = s_v[0][tid];
-        base[tid] = (base[tid] * d + n) / (d + 1e-6);
+        if (write_base) base[tid] = (base[tid] * d + n) / (d + 1e-6);
         part[3 + row0 + tid] = n;
     }
     if (blockIdx.x == 0 && tid == 0) {
         part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
-        result[0] = bv; result[1] = (double)(k_offset + bi);
+        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + bi); }
     }
 }
 
@@ -670,7 +613,7 @@ struct ModelOps {
     hipError_t (*advance_noise)(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                 const double* mean, double* log, int log_cap, int* log_count, int K, int k_offset, uint64_t seed,
                                 const int* next_step, const FilterCoefs& fc, void* eps, hipStream_t);
-    hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, double* base,
+    hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, int write_base, double* base,
                               double* part, double* result, hipStream_t);
 };
 
@@ -808,21 +751,21 @@ static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int d
 }
 template <class MD>
 static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset,
-                                     double* base, double* part, double* result, hipStream_t s) {
+                                     int write_base, double* base, double* part, double* result, hipStream_t s) {
     constexpr int NV = MD::NV;
     const int HM = H * NV;
     const dim3 block(K > 1024 ? 1024 : 256);
     // enough blocks to spread over the GPU: one per step once there are many planners, else one per entry
     if ((long)H * P >= 1024) {
         if (dtype == MPPI_F32)
-            hipLaunchKernelGGL((update_rows_kernel<float, NV, NV>), dim3(H, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, base, part, result);
+            hipLaunchKernelGGL((update_rows_kernel<float, NV, NV>), dim3(H, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
         else
-            hipLaunchKernelGGL((update_rows_kernel<double, NV, NV>), dim3(H, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, base, part, result);
+            hipLaunchKernelGGL((update_rows_kernel<double, NV, NV>), dim3(H, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
     } else {
         if (dtype == MPPI_F32)
-            hipLaunchKernelGGL((update_rows_kernel<float, NV, 1>), dim3(HM, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, base, part, result);
+            hipLaunchKernelGGL((update_rows_kernel<float, NV, 1>), dim3(HM, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
         else
-            hipLaunchKernelGGL((update_rows_kernel<double, NV, 1>), dim3(HM, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, base, part, result);
+            hipLaunchKernelGGL((update_rows_kernel<double, NV, 1>), dim3(HM, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
     }
     return hipGetLastError();
 }
@@ -862,7 +805,6 @@ struct mppi_planner {
     double* d_ref;
     int ref_cap;
     void* d_R;             // T [K]
-    double* d_S;           // [K]
     double* d_part;        // [3 + HM]
     double* d_result;      // [2] Rmax, argmax (after merge)
     void* d_obs;           // T [K][H][2M+6]
@@ -946,7 +888,6 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     HIP_OK(hipMemset(p->d_eps, 0, (size_t)p->HM * K * p->esz));
     HIP_OK(hipMalloc(&p->d_R, K * p->esz));
     HIP_OK(hipMemset(p->d_R, 0, K * p->esz));
-    HIP_OK(hipMalloc(&p->d_S, K * 8));
     HIP_OK(hipMalloc(&p->d_part, (3 * P + HM) * 8));
     HIP_OK(hipMemset(p->d_part, 0, (3 * P + HM) * 8));
     HIP_OK(hipMalloc(&p->d_result, 2 * 8 * P));
@@ -985,7 +926,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     delete p->h_state;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     if (p->step_graph) (void)hipGraphExecDestroy(p->step_graph);
-    void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R, p->d_S,
+    void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R,
                     p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -1190,21 +1131,13 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
 }
 
 static int launch_partials(mppi_planner* p, hipStream_t s) {
-    if (p->cfg.dtype == MPPI_F32) {
-        hipLaunchKernelGGL((weights_kernel<float>), dim3(p->P), dim3(1024), 0, s, (const float*)p->d_R, p->cfg.K, p->HM, p->cfg.kappa,
-                           p->cfg.k_offset, p->d_S, p->d_part);
-        hipLaunchKernelGGL((wsum_kernel<float>), dim3(p->HM, p->P), dim3(256), 0, s, p->d_S, (const float*)p->d_eps, p->cfg.K, p->d_part);
-    } else {
-        hipLaunchKernelGGL((weights_kernel<double>), dim3(p->P), dim3(1024), 0, s, (const double*)p->d_R, p->cfg.K, p->HM, p->cfg.kappa,
-                           p->cfg.k_offset, p->d_S, p->d_part);
-        hipLaunchKernelGGL((wsum_kernel<double>), dim3(p->HM, p->P), dim3(256), 0, s, p->d_S, (const double*)p->d_eps, p->cfg.K, p->d_part);
-    }
-    HIP_OK(hipGetLastError());
+    HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 0,
+                                      p->d_base, p->d_part, p->d_result, s));
     return 0;
 }
 
 static int launch_update_fused(mppi_planner* p, hipStream_t s) {
-    HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset,
+    HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 1,
                                       p->d_base, p->d_part, p->d_result, s));
     return 0;
 }

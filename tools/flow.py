@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Control-flow skeleton of one kernel in a device assembly listing: every label and branch with the number
-of instructions between them.    python tools/flow.py /tmp/mppi_quick.s 'rollout_kernelIfN4mppi11Reacher7DofELb1'"""
+of instructions between them (listing: make -C trajopt_amd/csrc asm).    python tools/flow.py /tmp/mppi_Reacher7Dof.s 'rollout_kernelIfN4mppi11Reacher7DofELb1'"""
 import re
 import sys
 

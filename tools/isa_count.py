@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction census of the kernels in a gfx950 assembly listing (hipcc -S)."""
 import collections, re, sys
-s = open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/mppi_hip.s").read()
+s = open(sys.argv[1] if len(sys.argv) > 1 else "/tmp/mppi_Reacher7Dof.s").read()
 pat = sys.argv[2] if len(sys.argv) > 2 else "rollout_kernel"
 for f in re.split(r"\n\s*\.globl\s+", s)[1:]:
     name = f.split("\n", 1)[0].strip()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """For every transcendental instruction of a kernel in an assembly listing: how many instructions later its
 result is first read (a lone wave stalls for the unit's latency when that distance is short).
-    python tools/trans_distance.py /tmp/mppi_quick.s 'rollout_kernelIfN4mppi11Reacher7DofELb1'"""
+    python tools/trans_distance.py /tmp/mppi_Reacher7Dof.s 'rollout_kernelIfN4mppi11Reacher7DofELb1'"""
 import re
 import sys
 from collections import Counter

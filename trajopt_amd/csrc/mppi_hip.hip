@@ -1,4 +1,5 @@
-// Device-resident MPPI planning step for MI355X (gfx950): kernels and C ABI.
+// Device-resident MPPI planning step for MI355X (gfx950): the C ABI and the model-independent kernels.
+// The per-model kernels live in kernels.hpp and are compiled once per model (model_ops.hip).
 //
 // Kernels (one lane = one sampled action sequence; wave = 64 samples):
 //   noise_upload_kernel / noise_philox_kernel   sigma scaling + recursive 3-tap filter, writes eps[t][j][k]
@@ -45,479 +46,12 @@ static int fail(int code, const std::string& msg) {
             return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
     } while (0)
 
-// ------------------------------------------------------------------------------------------
-// device-side state
-// ------------------------------------------------------------------------------------------
-struct DevState {
-    double q[MPPI_MAXV];
-    double v[MPPI_MAXV];
-    double target[3];
-    double alpha;
-    int timestep;
-    int ref_len;
-};
+#include "kernels.hpp"
 
-// ------------------------------------------------------------------------------------------
-// Philox-4x32-10
-// ------------------------------------------------------------------------------------------
-MPPI_HD void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-MPPI_HD void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
 extern "C" void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
     philox4x32_10(c, key[0], key[1]);
     for (int i = 0; i < 4; i++) out[i] = c[i];
-}
-
-// two uniforms -> two N(0,1) (Box-Muller) on the hardware transcendental units: log2, square root, and
-// sine / cosine of an angle given in revolutions (about 1e-6 absolute, far below what a sampler needs)
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-    const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);   // (0, 1]
-    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);          // [0, 1)
-    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
-    n0 = r * __builtin_amdgcn_cosf(u2);
-    n1 = r * __builtin_amdgcn_sinf(u2);
-}
-
-// ------------------------------------------------------------------------------------------
-// noise kernels: one lane per sample, recursion along t in registers
-// eps[t] = b0*sigma*z[t] + b1*eps[t-1] + b2*eps[t-2] for t >= 2 (rows 0, 1 unfiltered); separate
-// roundings for every product and sum so the fp64 path reproduces the host arithmetic bit for bit
-// ------------------------------------------------------------------------------------------
-struct FilterCoefs {
-    double sigma[MPPI_MAXV];
-    double b0, b1, b2;
-};
-
-template <class T, int NV>
-__global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restrict__ raw, int K, int H, FilterCoefs fc,
-                                                          int filter, T* __restrict__ eps) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
-    raw += (size_t)blockIdx.y * K * H * NV;           // planner blockIdx.y of a batched handle
-    eps += (size_t)blockIdx.y * H * NV * K;
-    double e1[NV], e2[NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++) e1[j] = e2[j] = 0.0;
-    for (int t = 0; t < H; t++) {
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            double e = raw[((size_t)k * H + t) * NV + j];
-            if (filter) {
-                e = __dmul_rn(e, fc.sigma[j]);
-                if (t >= 2) e = __dadd_rn(__dadd_rn(__dmul_rn(fc.b0, e), __dmul_rn(fc.b1, e1[j])), __dmul_rn(fc.b2, e2[j]));
-            }
-            e2[j] = e1[j];
-            e1[j] = e;
-            eps[((size_t)t * NV + j) * K + k] = T(e);
-        }
-    }
-}
-
-// one lane per (sample k, action dimension j): counter = (global k, j, block c, 0), block c holds the
-// draws of steps 4c .. 4c+3.  With seed_from_state the stream key is seed + the planner's current
-// timestep (the reference re-seeds every planning step with seed + t, trajopt/algos/mppi.py:130-132)
-template <class T, int NV>
-__device__ __forceinline__ void noise_philox_block(int block, int pl, int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
-                                                   int step, int seed_from_state, const FilterCoefs& fc, T* __restrict__ eps) {
-    const int idx = block * 256 + threadIdx.x;
-    if (idx >= K * NV) return;
-    const int j = idx / K, k = idx - j * K;
-    eps += (size_t)pl * H * NV * K;                   // planner of a batched handle: its own counter plane
-    if (seed_from_state) {
-        const uint64_t s = (((uint64_t)seed_hi << 32) | seed_lo) + (uint64_t)(int64_t)step;
-        seed_lo = (uint32_t)s;
-        seed_hi = (uint32_t)(s >> 32);
-    }
-    const double sigma = fc.sigma[j];
-    double e1 = 0.0, e2 = 0.0;
-    for (int c = 0; 4 * c < H; c++) {
-        uint32_t ctr[4] = {(uint32_t)(k_offset + k), (uint32_t)j, (uint32_t)c, (uint32_t)pl};
-        philox4x32_10(ctr, seed_lo, seed_hi);
-        float z[4];
-        box_muller(ctr[0], ctr[1], z[0], z[1]);
-        box_muller(ctr[2], ctr[3], z[2], z[3]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = 4 * c + u;
-            if (t < H) {
-                double e = (double)z[u] * sigma;
-                if (t >= 2) e = fc.b0 * e + fc.b1 * e1 + fc.b2 * e2;
-                e2 = e1;
-                e1 = e;
-                eps[((size_t)t * NV + j) * K + k] = T(e);
-            }
-        }
-    }
-}
-template <class T, int NV>
-__global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
-                                                           const DevState* __restrict__ st, int seed_from_state,
-                                                           FilterCoefs fc, T* __restrict__ eps) {
-    noise_philox_block<T, NV>(blockIdx.x, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, st[blockIdx.y].timestep, seed_from_state, fc, eps);
-}
-
-// ------------------------------------------------------------------------------------------
-// rollout
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool nonfinite(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
-__device__ __forceinline__ bool nonfinite(double x) {
-    return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
-}
-
-// LEAN: the planning configuration (dense reward, noise-relative samples, nothing dumped, no reference, no
-// critic) with those choices fixed at compile time: a lone wave pays about ten vector instructions' time for
-// every taken branch, and the general kernel spends eight per env step on options that are off.
-template <class T, class MD, bool LEAN>
-__global__ void __launch_bounds__(64)
-rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
-               const double* __restrict__ ref, int K, int H, int reward_type_, double gamma, int explicit_act_,
-               T* __restrict__ R, T* __restrict__ obs_, T* __restrict__ rew_, int* __restrict__ status,
-               T* __restrict__ fobs_, int* __restrict__ next_step) {
-    constexpr int NV = MD::NV, NQ = MD::NQ;
-    const int reward_type = LEAN ? int(REWARD_DENSE) : reward_type_;
-    const int explicit_act = LEAN ? 0 : explicit_act_;
-    T* __restrict__ obs = LEAN ? nullptr : obs_;
-    T* __restrict__ rew = LEAN ? nullptr : rew_;
-    T* __restrict__ fobs = LEAN ? nullptr : fobs_;
-    constexpr int OD = NQ + NV + 6;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    // index of the planning step after this one, for a noise generator that runs while the state advances
-    if (k == 0) next_step[blockIdx.y] = st[blockIdx.y].timestep + 1;
-    {   // planner blockIdx.y of a batched handle
-        const size_t pl = blockIdx.y;
-        st += pl; base += pl * H * NV; eps += pl * H * NV * K; R += pl * K;
-        if (obs) obs += pl * K * H * OD;
-        if (rew) rew += pl * K * H;
-        if (fobs) fobs += pl * K * OD;
-    }
-    T q[NQ], v[NV];
-    static_for<NQ>([&](auto Ic) { q[Ic] = T(st->q[Ic]); });
-    static_for<NV>([&](auto Ic) { v[Ic] = T(st->v[Ic]); });
-    RewardParams<T> rp;
-    rp.type = reward_type;
-    rp.alpha = T(st->alpha);
-    rp.target[0] = T(st->target[0]); rp.target[1] = T(st->target[1]); rp.target[2] = T(st->target[2]);
-    const int t0 = st->timestep, ref_len = LEAN ? 0 : st->ref_len;
-    const T gm = T(gamma);
-    T ret = T(0), g = T(1);
-    typename Step<T, MD>::Active act_rows;
-    act_rows.reset();
-    // the next step's noise and base action are fetched one step ahead: they do not depend on the
-    // state, and a lone wave has nobody to hide a load's latency behind
-    T a[NV];
-    static_for<NV>([&](auto Jc) { a[Jc] = explicit_act ? eps[(size_t)Jc * K + k] : T(base[Jc]) + eps[(size_t)Jc * K + k]; });
-    for (int t = 0; t < H; t++) {
-        // issued here, first touched after the step: a use at the top of the next iteration would make the
-        // wave wait for the scalar loads right behind their issue (the wait for the pre-loop loads sits there)
-        const int tn = (t + 1 < H) ? t + 1 : t;
-        T e_nx[NV];
-        double b_nx[NV];
-        static_for<NV>([&](auto Jc) {
-            constexpr int j = Jc;
-            e_nx[j] = eps[((size_t)tn * NV + j) * K + k];
-            b_nx[j] = base[tn * NV + j];
-        });
-        T rr[3] = {T(0), T(0), T(0)};
-        if (ref_len > 0) {
-            int idx = t0 + t + 1;
-            idx = idx < ref_len ? idx : ref_len - 1;
-            rr[0] = T(ref[3 * idx]); rr[1] = T(ref[3 * idx + 1]); rr[2] = T(ref[3 * idx + 2]);
-        }
-        Vec3<T> hand;
-        int ms = 0;
-        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_rows, ms);
-        // with a terminal-value critic the last reward is replaced by the critic's value (added by critic_kernel)
-        if (!(fobs && t == H - 1)) ret += g * r;
-        g *= gm;
-        static_for<NV>([&](auto Jc) { a[Jc] = explicit_act ? e_nx[Jc] : T(b_nx[Jc]) + e_nx[Jc]; });
-        if (fobs && t == H - 1) {
-            T* o = fobs + (size_t)k * OD;
-            static_for<NQ>([&](auto Ic) { o[Ic] = q[Ic]; });
-            static_for<NV>([&](auto Ic) { o[NQ + Ic] = v[Ic]; });
-            o[NQ + NV + 0] = hand.v[0]; o[NQ + NV + 1] = hand.v[1]; o[NQ + NV + 2] = hand.v[2];
-            o[NQ + NV + 3] = rp.target[0]; o[NQ + NV + 4] = rp.target[1]; o[NQ + NV + 5] = rp.target[2];
-        }
-        if (rew) rew[(size_t)k * H + t] = r;
-        if (obs) {
-            T* o = obs + ((size_t)k * H + t) * OD;
-            static_for<NQ>([&](auto Ic) { o[Ic] = q[Ic]; });
-            static_for<NV>([&](auto Ic) { o[NQ + Ic] = v[Ic]; });
-            o[NQ + NV + 0] = hand.v[0]; o[NQ + NV + 1] = hand.v[1]; o[NQ + NV + 2] = hand.v[2];
-            o[NQ + NV + 3] = rp.target[0]; o[NQ + NV + 4] = rp.target[1]; o[NQ + NV + 5] = rp.target[2];
-        }
-    }
-    R[k] = ret;
-    if (nonfinite(ret)) atomicOr(status, 1);
-}
-
-// one fp64 env.step of the real environment; io: in [q(nq) v(nv) target(3) act(nv) alpha refrow(3)],
-// out [q(nq) v(nv) obs(nq+nv+6) reward]
-template <class MD>
-__global__ void __launch_bounds__(64) env_step_kernel(const double* __restrict__ in, int reward_type, int has_ref, int forward_only,
-                                double* __restrict__ out) {
-    constexpr int NV = MD::NV, NQ = MD::NQ, S = NQ + NV;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double q[NQ], v[NV], a[NV];
-    static_for<NQ>([&](auto Ic) { q[Ic] = in[Ic]; });
-    static_for<NV>([&](auto Ic) { v[Ic] = in[NQ + Ic]; a[Ic] = in[S + 3 + Ic]; });
-    RewardParams<double> rp;
-    rp.type = reward_type;
-    rp.target[0] = in[S]; rp.target[1] = in[S + 1]; rp.target[2] = in[S + 2];
-    rp.alpha = in[S + NV + 3];
-    const double* rr = in + S + NV + 4;
-    Vec3<double> hand;
-    double r = 0.0;
-    if (forward_only) {
-        // sim.forward(): kinematics only; the substep leaves q, v untouched copies
-        double q2[NQ], v2[NV], z[NV];
-        static_for<NQ>([&](auto Ic) { q2[Ic] = q[Ic]; });
-        static_for<NV>([&](auto Ic) { v2[Ic] = v[Ic]; z[Ic] = 0.0; });
-        typename Step<double, MD>::Out o;
-        int sw;
-        typename Step<double, MD>::Active am;
-        am.reset();
-        Step<double, MD>::substep(q2, v2, z, true, o, am, sw);
-        hand = o.hand;
-    } else {
-        int ms = 0;
-        typename Step<double, MD>::Active am;
-        am.reset();
-        r = Env<double, MD>::step(q, v, a, rp, has_ref ? rr : nullptr, hand, am, ms);
-    }
-    static_for<NQ>([&](auto Ic) { out[Ic] = q[Ic]; out[S + Ic] = q[Ic]; });
-    static_for<NV>([&](auto Ic) { out[NQ + Ic] = v[Ic]; out[S + NQ + Ic] = v[Ic]; });
-    out[2 * S + 0] = hand.v[0]; out[2 * S + 1] = hand.v[1]; out[2 * S + 2] = hand.v[2];
-    out[2 * S + 3] = rp.target[0]; out[2 * S + 4] = rp.target[1]; out[2 * S + 5] = rp.target[2];
-    out[2 * S + 6] = r;
-}
-
-// Device-resident `advance_time` (trajopt/algos/mppi.py:67-89): lane 0 steps the real environment in fp64 with
-// act_sequence[0] from the planner's own state, appends (q', v', hand, target, reward, action) to the log ring and
-// stores the new state; then the whole block shifts the horizon and fills the tail.
-template <class MD>
-__device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st, double* __restrict__ base,
-                                              const double* __restrict__ ref, int reward_type, int H, int tail_mode,
-                                              const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                              int* __restrict__ log_count) {
-    constexpr int NV = MD::NV, NQ = MD::NQ;
-    constexpr int ROW = NQ + 2 * NV + 7;
-    constexpr int PER = 16;                       // H * NV <= 256 * PER
-    const int tid = threadIdx.x;
-    double keep[PER];
-    const int HM = H * NV;
-    st += pl; base += (size_t)pl * HM;                           // one block per planner
-    log += (size_t)pl * log_cap * ROW; log_count += pl;
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int i = tid + 256 * u;
-        double v = 0.0;
-        if (i < HM) {
-            const int t = i / NV, j = i - t * NV;
-            if (t < H - 1) v = base[(t + 1) * NV + j];
-            else v = (tail_mode == MPPI_TAIL_REPEAT) ? base[(H - 1) * NV + j] : mean[j];
-        }
-        keep[u] = v;
-    }
-    if (tid == 0) {
-        double q[NQ], v[NV], a[NV];
-        static_for<NQ>([&](auto Ic) { q[Ic] = st->q[Ic]; });
-        static_for<NV>([&](auto Ic) { v[Ic] = st->v[Ic]; a[Ic] = base[Ic]; });
-        RewardParams<double> rp;
-        rp.type = reward_type;
-        rp.alpha = st->alpha;
-        rp.target[0] = st->target[0]; rp.target[1] = st->target[1]; rp.target[2] = st->target[2];
-        double rr[3] = {0.0, 0.0, 0.0};
-        const int t0 = st->timestep, ref_len = st->ref_len;
-        if (ref_len > 0) {
-            int idx = t0 + 1;
-            idx = idx < ref_len ? idx : ref_len - 1;
-            rr[0] = ref[3 * idx]; rr[1] = ref[3 * idx + 1]; rr[2] = ref[3 * idx + 2];
-        }
-        Vec3<double> hand;
-        int ms = 0;
-        typename Step<double, MD>::Active am;
-        am.reset();
-        const double r = Env<double, MD>::step(q, v, a, rp, rr, hand, am, ms);
-        const int n = *log_count;
-        double* row = log + (size_t)(n % log_cap) * ROW;
-        static_for<NQ>([&](auto Ic) { row[Ic] = q[Ic]; st->q[Ic] = q[Ic]; });
-        static_for<NV>([&](auto Ic) { row[NQ + Ic] = v[Ic]; row[NQ + NV + 7 + Ic] = a[Ic]; st->v[Ic] = v[Ic]; });
-        row[NQ + NV + 0] = hand.v[0]; row[NQ + NV + 1] = hand.v[1]; row[NQ + NV + 2] = hand.v[2];
-        row[NQ + NV + 3] = rp.target[0]; row[NQ + NV + 4] = rp.target[1]; row[NQ + NV + 5] = rp.target[2];
-        row[NQ + NV + 6] = r;
-        st->timestep = t0 + 1;
-        *log_count = n + 1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int i = tid + 256 * u;
-        if (i < HM) base[i] = keep[u];
-    }
-}
-template <class MD>
-__global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
-                                                      const double* __restrict__ ref, int reward_type, int H, int tail_mode,
-                                                      const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                                      int* __restrict__ log_count) {
-    advance_block<MD>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
-}
-// advance_kernel and, in the blocks behind the first of every planner, the Philox noise of the NEXT planning step
-// (stream key seed + next_step[planner], published by the rollouts of the current step): the noise does not depend
-// on the new state, so it is drawn on otherwise idle CUs while one lane steps the real environment.
-template <class T, class MD>
-__global__ void __launch_bounds__(256) advance_noise_kernel(DevState* __restrict__ st, double* __restrict__ base,
-                                                            const double* __restrict__ ref, int reward_type, int H, int tail_mode,
-                                                            const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                                            int* __restrict__ log_count, int K, int k_offset, uint32_t seed_lo,
-                                                            uint32_t seed_hi, const int* __restrict__ next_step, FilterCoefs fc,
-                                                            T* __restrict__ eps) {
-    if (blockIdx.x == 0) advance_block<MD>(blockIdx.y, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
-    else noise_philox_block<T, MD::NV>(blockIdx.x - 1, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, next_step[blockIdx.y], 1, fc, eps);
-}
-
-// ------------------------------------------------------------------------------------------
-// terminal-value critic: tanh MLP in -> 128 -> 128 -> 1 on the final observation of every sample
-// (trajopt/models/critic_nets.py:47-60; input slices trajopt/algos/mppi.py:138-154), fp32 like the
-// reference's torch module.  One lane per sample; weights are wave-uniform (scalar loads).
-// R[k] += gamma^(H-1) * V(x_k): the rollout left the last reward out (trajopt/algos/mppi.py:97-101).
-// ------------------------------------------------------------------------------------------
-constexpr int CRITIC_INNER = 128;
-constexpr int CRITIC_IN = 17;          // widest input (qpos, qvel, goal); narrower inputs are zero padded
-
-template <class T, int NV>
-__global__ void __launch_bounds__(64) critic_kernel(const T* __restrict__ fobs, int K, int dim, const float* __restrict__ W1,
-                                                    const float* __restrict__ b1, const float* __restrict__ W2,
-                                                    const float* __restrict__ b2, const float* __restrict__ W3,
-                                                    double g_last, T* __restrict__ R) {
-    constexpr int OD = 2 * NV + 6;
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
-    fobs += (size_t)blockIdx.y * K * OD;
-    R += (size_t)blockIdx.y * K;
-    const T* o = fobs + (size_t)k * OD;
-    float x[CRITIC_IN];
-#pragma unroll
-    for (int i = 0; i < CRITIC_IN; i++) x[i] = 0.f;
-    if (dim == 14 || dim == 15 || dim == 17) {
-#pragma unroll
-        for (int i = 0; i < 14; i++) x[i] = (float)o[i];
-        if (dim == 15) {
-            const float dx = (float)o[OD - 6] - (float)o[OD - 3], dy = (float)o[OD - 5] - (float)o[OD - 2], dz = (float)o[OD - 4] - (float)o[OD - 1];
-            x[14] = sqrtf(dx * dx + dy * dy + dz * dz);
-        } else if (dim == 17) {
-            x[14] = (float)o[OD - 3]; x[15] = (float)o[OD - 2]; x[16] = (float)o[OD - 1];
-        }
-    } else if (dim == 3) {
-        x[0] = (float)o[OD - 6]; x[1] = (float)o[OD - 5]; x[2] = (float)o[OD - 4];
-    } else {  // 6
-#pragma unroll
-        for (int i = 0; i < 6; i++) x[i] = (float)o[OD - 6 + i];
-    }
-    float h1[CRITIC_INNER];
-#pragma unroll
-    for (int j = 0; j < CRITIC_INNER; j++) {
-        float a = b1[j];
-#pragma unroll
-        for (int i = 0; i < CRITIC_IN; i++) a = fmaf(W1[j * CRITIC_IN + i], x[i], a);
-        h1[j] = tanhf(a);
-    }
-    float out = W3[CRITIC_INNER];          // b3 follows W3 in the packed weight block
-    for (int j = 0; j < CRITIC_INNER; j++) {
-        float a = b2[j];
-#pragma unroll
-        for (int i = 0; i < CRITIC_INNER; i++) a = fmaf(W2[j * CRITIC_INNER + i], h1[i], a);
-        out = fmaf(W3[j], tanhf(a), out);
-    }
-    R[k] = R[k] + T(g_last) * T(out);
-}
-
-// ------------------------------------------------------------------------------------------
-// update kernels (fp64 accumulation, fixed reduction order -> bitwise reproducible)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void argmax_combine(double& v, int& i, double ov, int oi) {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-}
-__device__ __forceinline__ double shfl_xor_d(double x, int m) { return __shfl_xor(x, m, 64); }
-
-// Update in one launch (write_base = 1), or one shard's statistics (Rmax, arg-max, sum S, sum S eps) for the
-// exchange between ranks (write_base = 0: act_sequence is left to the merge).  A block owns ROWS consecutive (step, action dimension) rows of one planner:
-// it finds Rmax / first arg-max itself (every block gets the same values, in the same fixed order), evaluates
-// every weight S_k = exp(kappa (R_k - Rmax)) once and accumulates sum S and its ROWS weighted sums, then writes
-// its entries of act_sequence.  ROWS = NV (one block per step) when there are many planners to fill the GPU,
-// ROWS = 1 (one block per entry) for a single planner.  Any block size that is a multiple of 64 up to 1024.
-template <class T, int NV, int ROWS>
-__global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
-                                                           int k_offset, int HM, int write_base, double* __restrict__ base,
-                                                           double* __restrict__ part, double* __restrict__ result) {
-    __shared__ double s_v[16][ROWS + 1];
-    __shared__ int s_i[16];
-    const int row0 = blockIdx.x * ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + row0) * K;
-    base += (size_t)blockIdx.y * HM + row0; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
-    double bv = -DBL_MAX;
-    int bi = INT_MAX;
-    for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = shfl_xor_d(bv, m);
-        const int oi = __shfl_xor(bi, m, 64);
-        argmax_combine(bv, bi, ov, oi);
-    }
-    if (lane == 0) { s_v[wave][0] = bv; s_i[wave] = bi; }
-    __syncthreads();
-    bv = s_v[0][0]; bi = s_i[0];
-    for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
-    __syncthreads();
-    double acc[ROWS + 1];            // [ROWS]: sum of the weights
-#pragma unroll
-    for (int j = 0; j <= ROWS; j++) acc[j] = 0.0;
-    for (int k = tid; k < K; k += nthreads) {
-        const double sk = exp(kappa * ((double)R[k] - bv));
-#pragma unroll
-        for (int j = 0; j < ROWS; j++) acc[j] += sk * (double)eps[(size_t)j * K + k];
-        acc[ROWS] += sk;
-    }
-#pragma unroll
-    for (int j = 0; j <= ROWS; j++) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) acc[j] += shfl_xor_d(acc[j], m);
-        if (lane == 0) s_v[wave][j] = acc[j];
-    }
-    __syncthreads();
-    if (tid <= ROWS) {
-        double tot = 0.0;
-        for (int w = 0; w < nwaves; w++) tot += s_v[w][tid];
-        s_v[0][tid] = tot;                 // only thread tid reads column tid of the other rows
-    }
-    __syncthreads();
-    const double d = s_v[0][ROWS];
-    if (tid < ROWS) {
-        const double n = s_v[0][tid];
-        if (write_base) base[tid] = (base[tid] * d + n) / (d + 1e-6);
-        part[3 + row0 + tid] = n;
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
-        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + bi); }
-    }
 }
 
 // act_sequence = sum_k S_k (base + eps_k) / (sum S + 1e-6) from nranks shard statistics, rank order
@@ -588,196 +122,14 @@ __global__ void __launch_bounds__(256) update_direct_kernel(const double* __rest
     if (tid == 0) out[hm] = n / ((((s_v[0] + s_v[1]) + s_v[2]) + s_v[3]) + 1e-6);
 }
 
-// ------------------------------------------------------------------------------------------
-// per-model dispatch
-// ------------------------------------------------------------------------------------------
-struct RolloutArgs {
-    const DevState* st; const double* base; const void* eps; const double* ref;
-    int K, H, P, reward_type; double gamma; int explicit_act;
-    bool lean;      // dense reward, noise-relative samples, no dumps, no reference, no critic
-    void* R; void* obs; void* rew; int* status; void* fobs; int* next_step;
-};
-
-struct ModelOps {
-    const char* name;
-    int nv, nq;
-    bool (*matches)(const mppi_model_desc*, std::string&);
-    hipError_t (*rollout)(int dtype, const RolloutArgs&, hipStream_t);
-    hipError_t (*noise_upload)(int dtype, const double* raw, int K, int H, int P, const FilterCoefs&, int filter, void* eps, hipStream_t);
-    hipError_t (*noise_philox)(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st, int seed_from_state,
-                               const FilterCoefs&, void* eps, hipStream_t);
-    hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
-                          const double* mean, double* log, int log_cap, int* log_count, hipStream_t);
-    hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
-    hipError_t (*critic)(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t);
-    hipError_t (*advance_noise)(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
-                                const double* mean, double* log, int log_cap, int* log_count, int K, int k_offset, uint64_t seed,
-                                const int* next_step, const FilterCoefs& fc, void* eps, hipStream_t);
-    hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, int write_base, double* base,
-                              double* part, double* result, hipStream_t);
-};
-
-static bool near(double a, double b) { return std::fabs(a - b) <= 1e-12 * (1.0 + std::fabs(b)); }
-
-template <class MD> static bool model_matches(const mppi_model_desc* d, std::string& why) {
-    constexpr int NV = MD::NV;
-#define CHK(cond, what)                                                                     \
-    if (!(cond)) { why = std::string("model field differs from the compiled kernel: ") + what; return false; }
-    CHK(d->nv == NV, "nv");
-    CHK(d->nq == MD::NQ, "nq");
-    CHK(d->integrator == MD::INTEGRATOR, "integrator");
-    CHK(d->frame_skip == MD::FRAME_SKIP, "frame_skip");
-    CHK(near(d->h, MD::H), "timestep");
-    CHK(d->contact_link == MD::contact_link, "contact_link");
-    CHK(d->hand_link == MD::hand_link, "hand_link");
-    for (int i = 0; i < NV; i++) {
-        CHK(d->parent[i] == MD::parent[i], "parent");
-        CHK(d->jtype[i] == MD::jtype[i], "joint type");
-        CHK(d->qadr[i] == MD::qadr[i], "qpos address");
-        CHK((d->limited[i] != 0) == (MD::limited[i] != 0), "limited");
-        const double m = d->mass[i];
-        for (int c = 0; c < 3; c++) {
-            CHK(near(d->pos[i][c], MD::pos[i][c]), "pos");
-            CHK(near(d->axis[i][c], (c == MD::axis_id[i]) ? (double)MD::axis_sign[i] : 0.0), "axis");
-            CHK(near(m * d->com[i][c], MD::mc[i][c]), "com");
-        }
-        // rotational inertia about the link origin
-        const double* I = d->inertia[i];
-        const double* c = d->com[i];
-        const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
-        const double IO[6] = {I[0] + m * (cc - c[0] * c[0]), I[1] + m * (cc - c[1] * c[1]), I[2] + m * (cc - c[2] * c[2]),
-                              I[3] - m * c[0] * c[1],        I[4] - m * c[0] * c[2],        I[5] - m * c[1] * c[2]};
-        for (int e = 0; e < 6; e++) CHK(near(IO[e], MD::IO[i][e]), "inertia");
-        CHK(near(m, MD::mass[i]), "mass");
-        CHK(near(d->armature[i], MD::armature[i]), "armature");
-        CHK(near(d->damping[i], MD::damping[i]), "damping");
-        CHK(near(d->gear[i], MD::gear[i]), "gear");
-        CHK(near(d->ctrl_lo[i], MD::ctrl_lo[i]) && near(d->ctrl_hi[i], MD::ctrl_hi[i]), "ctrlrange");
-        if (MD::limited[i]) {
-            CHK(near(d->range_lo[i], MD::range_lo[i]) && near(d->range_hi[i], MD::range_hi[i]), "range");
-            CHK(near(d->dof_invweight[i], MD::dof_invweight[i]), "dof_invweight");
-        }
-    }
-    if (MD::contact_link >= 0) {
-        for (int c = 0; c < 3; c++) CHK(near(d->contact_pos[c], MD::contact_pos[c]), "contact_pos");
-        CHK(near(d->contact_radius, MD::contact_radius), "contact_radius");
-        CHK(near(d->contact_plane_z, MD::contact_plane_z), "contact_plane_z");
-        CHK(near(d->contact_margin, MD::contact_margin), "contact_margin");
-        CHK(near(d->contact_invweight, MD::contact_invweight), "contact_invweight");
-    }
-    for (int c = 0; c < 3; c++) CHK(near(d->hand_pos[c], MD::hand_pos[c]), "hand_pos");
-    for (int c = 0; c < 3; c++) CHK(near(d->gravity[c], MD::gravity[c]), "gravity");
-    CHK(near(d->solref_k, MD::solref_k) && near(d->solref_b, MD::solref_b), "solref");
-    for (int c = 0; c < 5; c++) CHK(near(d->solimp[c], MD::solimp[c]), "solimp");
-#undef CHK
-    return true;
-}
-
-template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArgs& a, hipStream_t s) {
-    const dim3 grid((a.K + 63) / 64, a.P), block(64);      // one wave per block: waves spread over CUs and XCDs
-    if (dtype == MPPI_F32 && a.lean)
-        hipLaunchKernelGGL((rollout_kernel<float, MD, true>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step);
-    else if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((rollout_kernel<float, MD, false>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step);
-    else
-        hipLaunchKernelGGL((rollout_kernel<double, MD, false>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs, a.next_step);
-    return hipGetLastError();
-}
-template <class MD>
-static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H, int P, const FilterCoefs& fc, int filter, void* eps,
-                                      hipStream_t s) {
-    const dim3 grid((K + 63) / 64, P), block(64);
-    if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((noise_upload_kernel<float, MD::NV>), grid, block, 0, s, raw, K, H, fc, filter, (float*)eps);
-    else
-        hipLaunchKernelGGL((noise_upload_kernel<double, MD::NV>), grid, block, 0, s, raw, K, H, fc, filter, (double*)eps);
-    return hipGetLastError();
-}
-template <class MD>
-static hipError_t launch_noise_philox(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st,
-                                      int seed_from_state, const FilterCoefs& fc, void* eps, hipStream_t s) {
-    const dim3 grid((K * MD::NV + 255) / 256, P), block(256);
-    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-    if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((noise_philox_kernel<float, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (float*)eps);
-    else
-        hipLaunchKernelGGL((noise_philox_kernel<double, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (double*)eps);
-    return hipGetLastError();
-}
-template <class MD>
-static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
-                                 const double* mean, double* log, int log_cap, int* log_count, hipStream_t s) {
-    hipLaunchKernelGGL((advance_kernel<MD>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
-    return hipGetLastError();
-}
-template <class MD>
-static hipError_t launch_advance_noise(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P,
-                                       int tail_mode, const double* mean, double* log, int log_cap, int* log_count, int K,
-                                       int k_offset, uint64_t seed, const int* next_step, const FilterCoefs& fc, void* eps,
-                                       hipStream_t s) {
-    const dim3 grid(1 + (K * MD::NV + 255) / 256, P), block(256);
-    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-    if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((advance_noise_kernel<float, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, K, k_offset, lo, hi, next_step, fc, (float*)eps);
-    else
-        hipLaunchKernelGGL((advance_noise_kernel<double, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, K, k_offset, lo, hi, next_step, fc, (double*)eps);
-    return hipGetLastError();
-}
-template <class MD>
-static hipError_t launch_env_step(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t s) {
-    hipLaunchKernelGGL((env_step_kernel<MD>), dim3(1), dim3(64), 0, s, in, reward_type, has_ref, forward_only, out);
-    return hipGetLastError();
-}
-// w: [W1 (128 x 17, zero padded) | b1 (128) | W2 (128 x 128) | b2 (128) | W3 (128) | b3 (1)]
-constexpr size_t CRITIC_W_FLOATS = CRITIC_INNER * CRITIC_IN + CRITIC_INNER + CRITIC_INNER * CRITIC_INNER + CRITIC_INNER + CRITIC_INNER + 1;
-template <class MD>
-static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t s) {
-    const float* W1 = w;
-    const float* b1 = W1 + CRITIC_INNER * CRITIC_IN;
-    const float* W2 = b1 + CRITIC_INNER;
-    const float* b2 = W2 + CRITIC_INNER * CRITIC_INNER;
-    const float* W3 = b2 + CRITIC_INNER;
-    const dim3 grid((K + 63) / 64, P), block(64);
-    if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((critic_kernel<float, MD::NV>), grid, block, 0, s, (const float*)fobs, K, dim, W1, b1, W2, b2, W3, g_last, (float*)R);
-    else
-        hipLaunchKernelGGL((critic_kernel<double, MD::NV>), grid, block, 0, s, (const double*)fobs, K, dim, W1, b1, W2, b2, W3, g_last, (double*)R);
-    return hipGetLastError();
-}
-template <class MD>
-static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset,
-                                     int write_base, double* base, double* part, double* result, hipStream_t s) {
-    constexpr int NV = MD::NV;
-    const int HM = H * NV;
-    const dim3 block(K > 1024 ? 1024 : 256);
-    // enough blocks to spread over the GPU: one per step once there are many planners, else one per entry
-    if ((long)H * P >= 1024) {
-        if (dtype == MPPI_F32)
-            hipLaunchKernelGGL((update_rows_kernel<float, NV, NV>), dim3(H, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-        else
-            hipLaunchKernelGGL((update_rows_kernel<double, NV, NV>), dim3(H, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-    } else {
-        if (dtype == MPPI_F32)
-            hipLaunchKernelGGL((update_rows_kernel<float, NV, 1>), dim3(HM, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-        else
-            hipLaunchKernelGGL((update_rows_kernel<double, NV, 1>), dim3(HM, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-    }
-    return hipGetLastError();
-}
-template <class MD> static ModelOps make_ops() {
-    return {MD::name, MD::NV, MD::NQ, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
-            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_advance_noise<MD>, &launch_update_rows<MD>};
-}
-#if defined(MPPI_ONLY_REACHER)      // quick builds for kernel experiments (make quick / make quickasm)
-static const ModelOps g_ops[] = {make_ops<Reacher7Dof>()};
+// one table per compiled model (model_ops.hip)
+extern const ModelOps mppi_ops_Reacher7Dof;
+#if defined(MPPI_ONLY_REACHER)      // quick builds for kernel experiments (make quick)
+static const ModelOps* const g_ops[] = {&mppi_ops_Reacher7Dof};
 #else
-static const ModelOps g_ops[] = {make_ops<Reacher7Dof>(), make_ops<Reacher7DofFree>(), make_ops<Tree18Dof>(), make_ops<Tree18DofQuat>(),
-                                 make_ops<Tree18DofRk4>()};
+extern const ModelOps mppi_ops_Reacher7DofFree, mppi_ops_Tree18Dof, mppi_ops_Tree18DofQuat, mppi_ops_Tree18DofRk4;
+static const ModelOps* const g_ops[] = {&mppi_ops_Reacher7Dof, &mppi_ops_Reacher7DofFree, &mppi_ops_Tree18Dof,
+                                        &mppi_ops_Tree18DofQuat, &mppi_ops_Tree18DofRk4};
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -840,7 +192,8 @@ const char* mppi_last_error(void) { return g_err.c_str(); }
 int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) {
     if (!desc || !out) return fail(-1, "null argument");
     std::string why = "unknown model name";
-    for (const ModelOps& o : g_ops) {
+    for (const ModelOps* op : g_ops) {
+        const ModelOps& o = *op;
         if (std::strncmp(desc->name, o.name, sizeof(desc->name)) != 0) continue;
         if (!o.matches(desc, why)) return fail(-3, std::string("model '") + o.name + "': " + why);
         mppi_model* m = new mppi_model();

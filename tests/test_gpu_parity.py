@@ -88,6 +88,42 @@ def test_rollouts_K160_H32(dev_model, oracle_sim, transitions, dtype, start):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_rollouts_away_from_every_limit(dev_model, oracle_sim, dtype):
+    """Whole waves without a single constraint row (the arm stays inside its joint ranges and off the table):
+    the step then takes its no-row path, which a wave of mixed samples never does."""
+    from trajopt_amd.model import get_model
+    md = get_model("reacher_7dof")
+    K, H = 128, 12
+    raw = ref_mppi.all_raw_normals(31, 32, 4, H, 7)
+    q0 = 0.5 * (md.range_lo + md.range_hi)
+    v0, tgt = np.zeros(7), np.array([0.2, -0.3, 0.1])
+    filt = [0.05 * np.ones(7), 0.25, 0.8, 0.0]
+    act = ref_mppi.filter_noise(raw.copy(), filt)
+    R_o, nobs_o, rew_o = oracle_sim.rollout(q0, v0, tgt, 0, act, dump=True, nthreads=4)
+    q_all = nobs_o[..., :7]
+    assert (q_all > md.range_lo + 1e-3).all() and (q_all < md.range_hi - 1e-3).all()      # no limit row anywhere
+    p = _planner(dev_model, K, H, dtype, dump=True, sigma=filt[0])
+    p.set_start_state(q0, v0, tgt, 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.upload_noise(raw)
+    p.rollout()
+    R, nobs = p.returns(), p.next_observations()
+    assert p.status() == 0
+    tol = 1e-10 if dtype == "f64" else 2e-5
+    assert (np.abs(nobs - nobs_o) / (1.0 + np.abs(nobs_o))).max() < tol
+    assert (np.abs(R - R_o) / np.abs(R_o)).max() < tol
+    p.close()
+    # the same through the planning-only kernel variant (nothing dumped)
+    p = _planner(dev_model, K, H, dtype, sigma=filt[0])
+    p.set_start_state(q0, v0, tgt, 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.upload_noise(raw)
+    p.rollout()
+    assert (np.abs(p.returns() - R_o) / np.abs(R_o)).max() < tol
+    p.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_iterate_matches_update(dev_model, oracle_sim, dtype):
     K, H = 160, 32
     raw = ref_mppi.all_raw_normals(7, 40, 4, H, 7)

@@ -124,6 +124,34 @@ def test_rollouts_away_from_every_limit(dev_model, oracle_sim, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_rollouts_on_the_table(dev_model, oracle_sim, transitions, dtype):
+    """The stored transition whose end effector is lowest: the contact sphere rests on the table, so the contact
+    row is part of the active-set solve (with joint-limit rows next to it) in a large share of the steps."""
+    K, H = 128, 16
+    hz = np.array([oracle_sim.fk_hand(q)[2] for q in transitions["qp"]])
+    i = int(np.argmin(hz))
+    q0, v0, tgt = transitions["qp"][i], transitions["qv"][i], transitions["target"][i]
+    raw = ref_mppi.all_raw_normals(5, 32, 4, H, 7)
+    act = ref_mppi.filter_noise(raw.copy(), FILTER)
+    R_o, nobs_o, rew_o = oracle_sim.rollout(q0, v0, tgt, 0, act, dump=True, nthreads=4)
+    assert (nobs_o[..., 16] < -0.343).mean() > 0.3            # sphere bottom within the contact margin of the plane
+    tol = 1e-10 if dtype == "f64" else 1e-4
+    for dump in (True, False):                                # general kernel, planning-only kernel
+        p = _planner(dev_model, K, H, dtype, dump=dump)
+        p.set_start_state(q0, v0, tgt, 0)
+        p.set_base_actions(np.zeros((H, 7)))
+        p.upload_noise(raw)
+        p.rollout()
+        R = p.returns()
+        assert p.status() == 0
+        assert (np.abs(R - R_o) / np.abs(R_o)).max() < tol
+        if dump:
+            nobs = p.next_observations()
+            assert (np.abs(nobs - nobs_o) / (1.0 + np.abs(nobs_o))).max() < tol
+        p.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_iterate_matches_update(dev_model, oracle_sim, dtype):
     K, H = 160, 32
     raw = ref_mppi.all_raw_normals(7, 40, 4, H, 7)

@@ -84,5 +84,5 @@ __global__ void __launch_bounds__(64) c_substep(const float* in, float* out) {
     typename S::Active am; am.reset(); int sw;
     S::substep(q, v, a, in[0] > 0, o, am, sw);
     static_for<NV>([&](auto I) { OUT(I) = q[I]; OUT(NV + I) = v[I]; });
-    OUT(1000) = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am.row[0] + am.row[NV];
+    OUT(1000) = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am.idle[0] + am.idle[NV];
 }

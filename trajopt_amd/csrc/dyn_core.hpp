@@ -274,12 +274,13 @@ template <class T, class MD> struct Step {
         T Jc[NV], Dc, arc;           // contact row: Jacobian, weight (0 = no row), reference acceleration
         Mask<T> any;
     };
-    // Which rows were active at the end of the previous substep, as 1 / 0 ([i]: limit row of joint i,
-    // [NV]: contact row).  Carried through a rollout as the starting guess of the active-set solve;
-    // rows that do not exist count as active, so that they start active when they next appear.
+    // Which rows ended the previous substep inactive ([i]: limit row of joint i, [NV]: contact row): the
+    // weight such a row was not given, > 0 only for a row that existed and was inactive.  Carried through a
+    // rollout as the starting guess of the active-set solve; every other row, the ones that did not exist
+    // included, starts active when it next appears.
     struct Active {
-        T row[NV + 1];
-        MPPI_HD void reset() { static_for<NV + 1>([&](auto Ic) { row[Ic] = T(1); }); }
+        T idle[NV + 1];
+        MPPI_HD void reset() { static_for<NV + 1>([&](auto Ic) { idle[Ic] = T(0); }); }
     };
 
     static MPPI_HD void frames(const T (&q)[NQ], Frames& fr) {
@@ -452,8 +453,10 @@ template <class T, class MD> struct Step {
         int sweeps = 0;
         if (MPPI_LIKELY(wave_any(r.any))) {
             // active weight of every row: its D while active, 0 while inactive or absent
-            T dg[NV], dc = act.row[NV] * r.Dc;
-            static_for<NV>([&](auto Ic) { dg[Ic] = act.row[Ic] * r.Dl[Ic]; });
+            T dg[NV], dc = sel(act.idle[NV] > T(0), T(0), r.Dc);
+            static_for<NV>([&](auto Ic) { dg[Ic] = sel(act.idle[Ic] > T(0), T(0), r.Dl[Ic]); });
+            T sa[NV];                                  // sign of J times reference acceleration, per limit row
+            static_for<NV>([&](auto Ic) { sa[Ic] = r.sg[Ic] * r.arl[Ic]; });
             T acc[NV], resl[NV], resc = T(0);
             // residual signs decide the next active set; true if this lane's set changed
             auto settle = [&]() -> Mask<T> {
@@ -484,7 +487,7 @@ template <class T, class MD> struct Step {
             auto sweep_all = [&](auto Wc) {
                 constexpr bool WC = decltype(Wc)::value;
                 auto right_hand_side = [&]() {
-                    static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + r.sg[Ic] * dg[Ic] * r.arl[Ic]; });
+                    static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + dg[Ic] * sa[Ic]; });
                     if constexpr (WC) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
                 };
                 sweeps = 1;
@@ -512,9 +515,9 @@ template <class T, class MD> struct Step {
                 const T f = -dc * resc;
                 static_for<NV>([&](auto Ic) { fc[Ic] += r.Jc[Ic] * f; });
             }
-            // rows that do not exist start active when they next appear
-            static_for<NV>([&](auto Ic) { act.row[Ic] = sel((r.Dl[Ic] > T(0)) & !(dg[Ic] > T(0)), T(0), T(1)); });
-            act.row[NV] = sel((r.Dc > T(0)) & !(dc > T(0)), T(0), T(1));
+            // the weight withheld from every row: positive for the inactive ones, zero for active and absent rows
+            static_for<NV>([&](auto Ic) { act.idle[Ic] = r.Dl[Ic] - dg[Ic]; });
+            act.idle[NV] = r.Dc - dc;
         } else {
             act.reset();
             factor_damped(M, damped);

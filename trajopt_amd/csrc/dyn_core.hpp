@@ -72,6 +72,10 @@ MPPI_HD float rcp_t(float x) {
 #endif
 }
 MPPI_HD double rcp_t(double x) { return 1.0 / x; }
+MPPI_HD float min_t(float a, float b) { return fminf(a, b); }
+MPPI_HD double min_t(double a, double b) { return fmin(a, b); }
+MPPI_HD float max_t(float a, float b) { return fmaxf(a, b); }
+MPPI_HD double max_t(double a, double b) { return fmax(a, b); }
 MPPI_HD float abs_t(float x) { return fabsf(x); }
 MPPI_HD double abs_t(double x) { return fabs(x); }
 
@@ -336,7 +340,7 @@ template <class T, class MD> struct Step {
         // the model and its reference acceleration two multiply-adds; only when some lane of the wave has a
         // row inside the ramp is the impedance polynomial evaluated (same values either way).
         T pos[NV];
-        Mask<T> ramp{};
+        T shallowest = T(-1e30);      // the least negative violated distance: inside the ramp iff above -width
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
             r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1); pos[i] = T(0);
@@ -344,14 +348,14 @@ template <class T, class MD> struct Step {
                 static_assert(!is_ball(i), "ball joints have no limit rows");
                 const T lo = q[MD::qadr[i]] - T(MD::range_lo[i]);
                 const T hi = T(MD::range_hi[i]) - q[MD::qadr[i]];
-                const Mask<T> blo = lo < hi;
-                pos[i] = sel(blo, lo, hi);
-                r.sg[i] = sel(blo, T(1), T(-1));
-                r.any |= pos[i] < T(0);
-                ramp |= (pos[i] < T(0)) & (pos[i] > T(-MD::solimp[2]));
+                pos[i] = min_t(lo, hi);
+                r.sg[i] = sel(lo < hi, T(1), T(-1));
+                const Mask<T> on = pos[i] < T(0);
+                r.any |= on;
+                shallowest = max_t(shallowest, sel(on, pos[i], T(-1e30)));
             }
         });
-        if (MPPI_UNLIKELY(wave_any(ramp))) {
+        if (MPPI_UNLIKELY(wave_any(shallowest > T(-MD::solimp[2])))) {
             static_for<NV>([&](auto Ic) {
                 constexpr int i = Ic;
                 if constexpr (MD::limited[i] != 0) {

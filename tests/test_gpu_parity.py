@@ -151,6 +151,29 @@ def test_rollouts_on_the_table(dev_model, oracle_sim, transitions, dtype):
         p.close()
 
 
+@pytest.mark.parametrize("H,P", [(45, 1), (64, 1), (75, 1), (21, 3), (40, 2)])
+def test_update_block_shapes(dev_model, H, P):
+    """The update kernel gives every block one, two or four rows of act_sequence depending on how many there
+    are, and the last block of a planner may own fewer: horizons on both sides of every boundary, odd row
+    counts included, single and batched planners, against the numpy restatement on the device's own returns."""
+    K = 192
+    rs = np.random.RandomState(H)
+    p = _planner(dev_model, K, H, "f64", planners=P) if P > 1 else _planner(dev_model, K, H, "f64")
+    lead = (P,) if P > 1 else ()
+    base = rs.randn(*(lead + (H, 7))) * 0.3
+    p.set_start_state(np.zeros(lead + (7,)), np.zeros(lead + (7,)), np.zeros(lead + (3,)) + 0.1, 0)
+    p.set_base_actions(base)
+    p.generate_noise(11)
+    acts = p.actions()                 # base + eps, read before the update replaces base
+    p.iterate(1)
+    R, seq = p.returns(), p.act_sequence()
+    for b in range(P):
+        Rb, ab, sb = (R[b], acts[b], seq[b]) if P > 1 else (R, acts, seq)
+        want = ref_mppi.update(ab, Rb, 25.0)
+        assert np.abs(sb - want).max() < 1e-11, (H, P, b)
+    p.close()
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_iterate_matches_update(dev_model, oracle_sim, dtype):
     K, H = 160, 32

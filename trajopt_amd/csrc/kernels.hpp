@@ -427,7 +427,9 @@ __device__ __forceinline__ double shfl_xor_d(double x, int m) { return __shfl_xo
 // it finds Rmax / first arg-max itself (every block gets the same values, in the same fixed order), evaluates
 // every weight S_k = exp(kappa (R_k - Rmax)) once and accumulates sum S and its ROWS weighted sums, then writes
 // its entries of act_sequence.  ROWS = NV (one block per step) when there are many planners to fill the GPU,
-// ROWS = 1 (one block per entry) for a single planner.  Any block size that is a multiple of 64 up to 1024.
+// ROWS = 1, 2 or 4 for few planners: as many blocks as there are CUs, no more (every block evaluates all K
+// weights, which is most of its time; a second block on a CU doubles the kernel's).  The last block of a
+// planner may own fewer rows.  Any block size that is a multiple of 64 up to 1024.
 template <class T, int NV, int ROWS>
 __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
                                                            int k_offset, int HM, int write_base, double* __restrict__ base,
@@ -436,6 +438,7 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     __shared__ int s_i[16];
     const int row0 = blockIdx.x * ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int nr = HM - row0 < ROWS ? HM - row0 : ROWS;       // rows this block owns
     R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + row0) * K;
     base += (size_t)blockIdx.y * HM + row0; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
     double bv = -DBL_MAX;
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     for (int k = tid; k < K; k += nthreads) {
         const double sk = exp(kappa * ((double)R[k] - bv));
 #pragma unroll
-        for (int j = 0; j < ROWS; j++) acc[j] += sk * (double)eps[(size_t)j * K + k];
+        for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk * (double)eps[(size_t)j * K + k];
         acc[ROWS] += sk;
     }
 #pragma unroll
@@ -475,7 +478,7 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     }
     __syncthreads();
     const double d = s_v[0][ROWS];
-    if (tid < ROWS) {
+    if (tid < nr) {
         const double n = s_v[0][tid];
         if (write_base) base[tid] = (base[tid] * d + n) / (d + 1e-6);
         part[3 + row0 + tid] = n;
@@ -654,17 +657,22 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
     const int HM = H * NV;
     const dim3 block(K > 1024 ? 1024 : 256);
     // enough blocks to spread over the GPU: one per step once there are many planners, else one per entry
-    if ((long)H * P >= 1024) {
-        if (dtype == MPPI_F32)
-            hipLaunchKernelGGL((update_rows_kernel<float, NV, NV>), dim3(H, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-        else
-            hipLaunchKernelGGL((update_rows_kernel<double, NV, NV>), dim3(H, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-    } else {
-        if (dtype == MPPI_F32)
-            hipLaunchKernelGGL((update_rows_kernel<float, NV, 1>), dim3(HM, P), block, 0, s, (const float*)R, (const float*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-        else
-            hipLaunchKernelGGL((update_rows_kernel<double, NV, 1>), dim3(HM, P), block, 0, s, (const double*)R, (const double*)eps, K, kappa, k_offset, HM, write_base, base, part, result);
-    }
+#define MPPI_LAUNCH_UPDATE(ROWS_)                                                                                               \
+    do {                                                                                                                        \
+        const dim3 grid((HM + (ROWS_) - 1) / (ROWS_), P);                                                                       \
+        if (dtype == MPPI_F32)                                                                                                  \
+            hipLaunchKernelGGL((update_rows_kernel<float, NV, ROWS_>), grid, block, 0, s, (const float*)R, (const float*)eps,  \
+                               K, kappa, k_offset, HM, write_base, base, part, result);                                        \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((update_rows_kernel<double, NV, ROWS_>), grid, block, 0, s, (const double*)R, (const double*)eps, \
+                               K, kappa, k_offset, HM, write_base, base, part, result);                                        \
+    } while (0)
+    const int cus = 256;
+    if ((long)H * P >= 1024) MPPI_LAUNCH_UPDATE(NV);                        // many planners: one block per step
+    else if ((long)HM * P <= cus) MPPI_LAUNCH_UPDATE(1);
+    else if ((long)((HM + 1) / 2) * P <= cus) MPPI_LAUNCH_UPDATE(2);
+    else MPPI_LAUNCH_UPDATE(4);
+#undef MPPI_LAUNCH_UPDATE
     return hipGetLastError();
 }
 template <class MD> static ModelOps make_ops() {

@@ -441,9 +441,31 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     const int nr = HM - row0 < ROWS ? HM - row0 : ROWS;       // rows this block owns
     R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + row0) * K;
     base += (size_t)blockIdx.y * HM + row0; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
+    // Up to HOLD samples per thread stay in registers: the returns are read once, and the noise rows are
+    // requested before the reduction that finds the maximum, so their latency is spent there.
+    constexpr int HOLD = 4;
+    const bool held = K <= HOLD * nthreads;
+    T rv[HOLD], ev[ROWS][HOLD];
+    if (held) {
+#pragma unroll
+        for (int e = 0; e < HOLD; e++) {
+            const int k = tid + e * nthreads;
+            rv[e] = k < K ? R[k] : T(0);
+#pragma unroll
+            for (int j = 0; j < ROWS; j++) ev[j][e] = (k < K && j < nr) ? eps[(size_t)j * K + k] : T(0);
+        }
+    }
     double bv = -DBL_MAX;
     int bi = INT_MAX;
-    for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
+    if (held) {
+#pragma unroll
+        for (int e = 0; e < HOLD; e++) {
+            const int k = tid + e * nthreads;
+            if (k < K) argmax_combine(bv, bi, (double)rv[e], k);
+        }
+    } else {
+        for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const double ov = shfl_xor_d(bv, m);
@@ -458,11 +480,24 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     double acc[ROWS + 1];            // [ROWS]: sum of the weights
 #pragma unroll
     for (int j = 0; j <= ROWS; j++) acc[j] = 0.0;
-    for (int k = tid; k < K; k += nthreads) {
-        const double sk = exp(kappa * ((double)R[k] - bv));
+    if (held) {
 #pragma unroll
-        for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk * (double)eps[(size_t)j * K + k];
-        acc[ROWS] += sk;
+        for (int e = 0; e < HOLD; e++) {
+            const int k = tid + e * nthreads;
+            if (k < K) {
+                const double sk = exp(kappa * ((double)rv[e] - bv));
+#pragma unroll
+                for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk * (double)ev[j][e];
+                acc[ROWS] += sk;
+            }
+        }
+    } else {
+        for (int k = tid; k < K; k += nthreads) {
+            const double sk = exp(kappa * ((double)R[k] - bv));
+#pragma unroll
+            for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk * (double)eps[(size_t)j * K + k];
+            acc[ROWS] += sk;
+        }
     }
 #pragma unroll
     for (int j = 0; j <= ROWS; j++) {

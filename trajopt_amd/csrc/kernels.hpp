@@ -438,13 +438,15 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     __shared__ int s_i[16];
     const int row0 = blockIdx.x * ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    const int nr = HM - row0 < ROWS ? HM - row0 : ROWS;       // rows this block owns
+    // rows this block owns (HM is a multiple of NV, so the one-block-per-step shape always owns all of its rows)
+    const int nr = (ROWS == NV || HM - row0 >= ROWS) ? ROWS : HM - row0;
     R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + row0) * K;
     base += (size_t)blockIdx.y * HM + row0; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
     // Up to HOLD samples per thread stay in registers: the returns are read once, and the noise rows are
     // requested before the reduction that finds the maximum, so their latency is spent there.
     constexpr int HOLD = 4;
-    const bool held = K <= HOLD * nthreads;
+    // (not for the one-block-per-step shape of large batches: that one streams, and lives on occupancy)
+    const bool held = ROWS <= 4 && K <= HOLD * nthreads;
     T rv[HOLD], ev[ROWS][HOLD];
     if (held) {
 #pragma unroll

@@ -9,6 +9,8 @@ device and enqueued on one stream without host synchronisation: Philox noise + f
 K x H rollouts with fused reward / discounted return, max / weights / weighted action sum,
 (N > 1: one RCCL all-gather of the per-rank statistics), merge into act_sequence, the single
 fp64 step of the real environment from the planner's own state, and the horizon shift.
+On one GPU a step is one `mppi_plan` call (a hipGraph replay; every 8th step is launched kernel
+by kernel with HIP events around the rollout kernel, which gives roofline.kernel_ms).
 With N ranks each rank rolls out its own K = 4096 shard of a 4096*N-sample planner (weak
 scaling); sample noise is addressed by global index so the result does not depend on N.
 
@@ -152,24 +154,27 @@ def main():
         part = p.partials_tensor()
         gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
 
-    profiling = [True]        # kernel timing by HIP events needs individual launches (set False to replay a graph)
+    # One GPU: every step is mppi_plan (noise ahead, rollouts, update, real-env step, shift).  It replays one captured
+    # hipGraph per step; on every PROFILE_EVERY-th step it launches the same kernels one by one instead, with HIP
+    # events around the rollout kernel (a graph replay cannot be timed from inside), which is where
+    # roofline.kernel_ms comes from.  Several ranks: the exchange sits between the kernels, so they are launched
+    # one by one on every step, all of them timed.
+    PROFILE_EVERY = 8
 
-    def planning_step():
+    def planning_step(i):
         # everything below is enqueued on one stream; there is no host synchronisation inside a step
-        if not sharded and not profiling[0]:
-            p.plan(SEED, 1, 1, sptr)                 # the same sequence as below, as one hipGraph replay
+        if not sharded:
+            p.profile(timed[0] and i % PROFILE_EVERY == 0)
+            p.plan(SEED, 1, 1, sptr)
             return
         # the Philox noise of this step (key = SEED + timestep, read on the device) was drawn by the previous
-        # step's advance launch, next to the real-env step; the first step draws its own below
-        if not sharded:
-            p.iterate(1, sptr)                       # rollouts + fused update
+        # step's advance launch, next to the real-env step; the first step draws its own (before the loop)
+        p.local_partials(sptr)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, part)
         else:
-            p.local_partials(sptr)
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, part)
-            else:
-                dist.all_gather(list(gathered.view(world, -1).unbind(0)), part)
-            p.merge(gathered.data_ptr(), world, sptr)
+            dist.all_gather(list(gathered.view(world, -1).unbind(0)), part)
+        p.merge(gathered.data_ptr(), world, sptr)
         p.advance_noise(SEED, sptr)                  # real env fp64 step with act_sequence[0], log, horizon shift,
                                                      # and the next step's noise on the idle CUs of the same launch
 
@@ -178,15 +183,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    p.generate_noise_step(SEED, sptr)
-    for _ in range(args.warmup):
-        planning_step()
-    p.profile(True)
+    timed = [False]
+    if sharded:
+        p.generate_noise_step(SEED, sptr)
+    for i in range(args.warmup):
+        planning_step(i)
+    timed[0] = True
+    p.profile(sharded)
     p.profile_read()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        planning_step()
+    for i in range(args.steps):
+        planning_step(i)
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, launches = p.profile_read()

@@ -127,7 +127,8 @@ def main():
     from trajopt_amd.device import DeviceModel, DevicePlanner
 
     # MPPI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
-    # devices round-robin; the exchange goes through host memory); the measured configuration is RCCL ("nccl")
+    # devices round-robin and are time-sliced by the driver, the exchange goes through host memory: a functional
+    # check whose timings mean nothing); the measured configuration is RCCL ("nccl"), one rank per GPU
     backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)

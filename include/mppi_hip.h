@@ -25,6 +25,7 @@ extern "C" {
 #define MPPI_MAXV 32
 #define MPPI_ABI_VERSION 4
 #define MPPI_LOG_CAP 4096
+#define MPPI_NOALLOC_MAX_K 262144   /* most samples mppi_update_from_returns_noalloc accepts */
 
 enum { MPPI_F32 = 0, MPPI_F64 = 1 };
 enum { MPPI_REWARD_DENSE = 0, MPPI_REWARD_SPARSE = 1, MPPI_REWARD_TRACKING = 2, MPPI_REWARD_COOLING = 3 };
@@ -211,6 +212,18 @@ int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, do
  * actions (K, H*M), returns R (K) -> act_sequence (H*M), computed on the device. */
 int mppi_update_from_returns(int32_t device, const double* act_KxHM, const double* R, int32_t K, int32_t HM,
                              double kappa, double* act_seq_out);
+
+/* The arithmetic of mppi_update_from_returns for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * Inputs and the output are DEVICE pointers (actions (K, H*M), returns (K), act_sequence (H*M)); the two kernels
+ * are enqueued on `stream` (NULL: the default stream) and nothing is synchronised, allocated or freed.  The
+ * weights S_k live in a fixed array in the library's device image, (MPPI_NOALLOC_MAX_K + 32) doubles = 2 MiB on
+ * every GPU the library runs on, held until the process ends; K above MPPI_NOALLOC_MAX_K is rejected (-6).
+ * All calls on one GPU share that array: calls whose kernels may overlap on one GPU (different streams or
+ * host threads) race and must be ordered by the caller.  The array's address is looked up once per device, at
+ * mppi_planner_create or at the first call on that device (which should therefore be made before a capture). */
+int mppi_update_from_returns_noalloc(int32_t device, const double* d_act_KxHM, const double* d_R, int32_t K, int32_t HM,
+                                     double kappa, double* d_act_seq_out, void* stream);
 
 /* Philox-4x32-10 block function (host), for known-answer tests of the device generator. */
 void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -9,6 +9,7 @@ import os
 import numpy as np
 
 MAXV = 32
+NOALLOC_MAX_K = 262144
 _d, _i32, _u64, _vp = C.c_double, C.c_int32, C.c_uint64, C.c_void_p
 
 F32, F64 = 0, 1
@@ -82,6 +83,7 @@ _PROTOS = {
     "mppi_env_step": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _d, _vp, _vp, _vp, _vp]),
     "mppi_env_forward": (C.c_int, [_vp, _i32, _vp, _vp]),
     "mppi_update_from_returns": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _d, _vp]),
+    "mppi_update_from_returns_noalloc": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _d, _vp, _vp]),
     "mppi_philox4x32": (None, [_vp, _vp, _vp]),
 }
 EXPORTS = tuple(_PROTOS)

@@ -22,6 +22,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -122,6 +123,74 @@ __global__ void __launch_bounds__(256) update_direct_kernel(const double* __rest
     if (tid == 0) out[hm] = n / ((((s_v[0] + s_v[1]) + s_v[2]) + s_v[3]) + 1e-6);
 }
 
+// ------------------------------------------------------------------------------------------
+// `MPPI.update` without any allocation: the weights S_k and their sum live in a fixed per-GPU buffer
+// ------------------------------------------------------------------------------------------
+// [0] Rmax, [1] sum S, [NOALLOC_HEAD + k] S_k.  Every GPU the library runs on holds its own copy of this array
+// until the process ends; host code reaches it only through the address hipGetSymbolAddress returns for the
+// current device (noalloc_scratch below), never through the array's name.
+constexpr int NOALLOC_HEAD = 32;
+static __device__ __align__(256) double scratch[MPPI_NOALLOC_MAX_K + NOALLOC_HEAD];
+
+// S_k = exp(kappa (R_k - Rmax)) and sum S, in the summation order of update_direct_kernel (one block of 256)
+__global__ void __launch_bounds__(256) noalloc_weights_kernel(const double* __restrict__ R, int K, double kappa,
+                                                              double* __restrict__ ws) {
+    __shared__ double s_v[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double bv = -DBL_MAX;
+    for (int k = tid; k < K; k += 256) bv = R[k] > bv ? R[k] : bv;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const double o = shfl_xor_d(bv, m); bv = o > bv ? o : bv; }
+    if (lane == 0) s_v[wave] = bv;
+    __syncthreads();
+    bv = s_v[0];
+    for (int w = 1; w < 4; w++) bv = s_v[w] > bv ? s_v[w] : bv;
+    __syncthreads();
+    double den = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const double s = exp(kappa * (R[k] - bv));
+        ws[NOALLOC_HEAD + k] = s;
+        den += s;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) den += shfl_xor_d(den, m);
+    if (lane == 0) s_v[wave] = den;
+    __syncthreads();
+    if (tid == 0) { ws[0] = bv; ws[1] = ((s_v[0] + s_v[1]) + s_v[2]) + s_v[3]; }
+}
+// out[hm] = sum_k S_k act[k][hm] / (sum S + 1e-6): block hm, same order as update_direct_kernel
+__global__ void __launch_bounds__(256) noalloc_sum_kernel(const double* __restrict__ act, const double* __restrict__ ws,
+                                                          int K, int HM, double* __restrict__ out) {
+    __shared__ double s_v[4];
+    const int hm = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double num = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const double s = ws[NOALLOC_HEAD + k];
+        num += s * act[(size_t)k * HM + hm];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) num += shfl_xor_d(num, m);
+    if (lane == 0) s_v[wave] = num;
+    __syncthreads();
+    if (tid == 0) out[hm] = (((s_v[0] + s_v[1]) + s_v[2]) + s_v[3]) / (ws[1] + 1e-6);
+}
+
+// Device address of `scratch` on the given device (which the caller has made current), resolved once per device.
+static double* g_scratch_ptr[16];
+static std::mutex g_scratch_mu;
+static int noalloc_scratch(int device, double** out) {
+    if (device < 0 || device >= 16) return fail(-1, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_OK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(-2, "hipGetSymbolAddress returned a null address for the update workspace");
+        g_scratch_ptr[device] = (double*)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
 // one table per compiled model (model_ops.hip)
 extern const ModelOps mppi_ops_Reacher7Dof;
 #if defined(MPPI_ONLY_REACHER)      // quick builds for kernel experiments (make quick)
@@ -218,6 +287,11 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     if (cfg->K < 1 || cfg->H < 1) return fail(-1, "K and H must be positive");
     if (cfg->dtype != MPPI_F32 && cfg->dtype != MPPI_F64) return fail(-1, "dtype must be MPPI_F32 or MPPI_F64");
     HIP_OK(hipSetDevice(cfg->device));
+    {   // set-up time is when the no-allocation update's workspace address is looked up for this device
+        double* ws;
+        const int rc = noalloc_scratch(cfg->device, &ws);
+        if (rc) return rc;
+    }
     mppi_planner* p = new mppi_planner();
     std::memset(p, 0, sizeof(*p));
     p->model = m;
@@ -830,6 +904,25 @@ int mppi_update_from_returns(int32_t device, const double* act, const double* R,
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpy(act_seq_out, d_out, (size_t)HM * 8, hipMemcpyDeviceToHost));
     HIP_OK(hipFree(d_act)); HIP_OK(hipFree(d_R)); HIP_OK(hipFree(d_out));
+    return 0;
+}
+
+int mppi_update_from_returns_noalloc(int32_t device, const double* d_act, const double* d_R, int32_t K, int32_t HM,
+                                     double kappa, double* d_act_seq_out, void* stream) {
+    if (!d_act || !d_R || !d_act_seq_out || K < 1 || HM < 1) return fail(-1, "bad argument");
+    if (K > MPPI_NOALLOC_MAX_K)
+        return fail(-6, "mppi_update_from_returns_noalloc: K = " + std::to_string(K) + " exceeds the fixed workspace of " +
+                            std::to_string(MPPI_NOALLOC_MAX_K) + " samples; use mppi_update_from_returns");
+    HIP_OK(hipSetDevice(device));
+    double* ws;
+    const int rc = noalloc_scratch(device, &ws);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // both kernels overwrite every workspace entry they later read (Rmax, sum S, S_0 .. S_{K-1}): nothing has to be cleared
+    hipLaunchKernelGGL(noalloc_weights_kernel, dim3(1), dim3(256), 0, s, d_R, (int)K, kappa, ws);
+    HIP_OK(hipGetLastError());
+    hipLaunchKernelGGL(noalloc_sum_kernel, dim3(HM), dim3(256), 0, s, d_act, (const double*)ws, (int)K, (int)HM, d_act_seq_out);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 

@@ -38,9 +38,14 @@ enum {
     MPPI_READ_ACTIONS = 3,      /* double[K*H*M]        perturbed actions, sample-major (K,H,M)         */
     MPPI_READ_NEXT_OBS = 4,     /* double[K*H*(nq+M+6)] next_observations (needs cfg.dump); nq = M without balls */
     MPPI_READ_REWARDS = 5,      /* double[K*H]          per-step rewards (needs cfg.dump)               */
-    MPPI_READ_STATUS = 6,       /* int32[1]             bit0: non-finite return seen                    */
+    MPPI_READ_STATUS = 6,       /* int32[1]             MPPI_STATUS_* bits, sticky since the planner was created */
     MPPI_READ_RMAX = 7,         /* double[1]            best return                                      */
     MPPI_READ_PARTIALS = 8      /* double[3+H*M]        this shard's (Rmax, argmax, den, num[H*M])      */
+};
+
+enum {
+    MPPI_STATUS_NONFINITE = 1,  /* a rollout returned NaN or infinity                                             */
+    MPPI_STATUS_SWEEP_CAP = 2   /* an active-set solve of the constraint rows stopped at cfg.sweep_cap sweeps     */
 };
 
 /* Flat model: one link per hinge or slide joint (welded bodies merged), the data the reference hands
@@ -95,8 +100,10 @@ typedef struct mppi_planner_cfg {
     int32_t k_offset;      /* global index of local sample 0 (sharded planners)            */
     int32_t dump;          /* keep next_observations / rewards of every rollout            */
     int32_t P;             /* independent planners batched in this handle (0 or 1: one).   */
-    int32_t reserved;      /*   Every per-planner array argument / result then holds the P */
+                           /*   Every per-planner array argument / result then holds the P */
                            /*   planners back to back; noise streams differ per planner.   */
+    int32_t sweep_cap;     /* most sweeps of the constraint rows' active-set iteration per  */
+                           /*   physics substep; 0: the default, 12                        */
     double kappa;
     double gamma;
     double sigma[MPPI_MAXV];   /* filter_coefs[0]                                          */

@@ -197,13 +197,49 @@ def test_continual_env_resets_target_every_50_real_steps():
     for _ in range(49):
         e.step(np.zeros(7))
     assert np.array_equal(e.get_env_state()['target_pos'], first)
-    e.step(np.zeros(7))                                   # 50th real step draws a new target
+    ob, _, _, infos = e.step(np.zeros(7))                 # 50th real step draws a new target
     assert not np.array_equal(e.get_env_state()['target_pos'], first)
+    # the observation predates the redraw, the infos carry the new target (continual_reacher_env.py:15-23)
+    assert np.array_equal(ob[-3:], first) and np.array_equal(infos['state']['target_pos'], e.get_env_state()['target_pos'])
     e.real_step = False                                    # rollout envs never move the target
     t = e.get_env_state()['target_pos'].copy()
     for _ in range(50):
         e.step(np.zeros(7))
     assert np.array_equal(e.get_env_state()['target_pos'], t)
+
+
+def test_continual_env_plans_on_the_dense_reward_whatever_reward_type_says():
+    """`get_environment('continual_reacher_7dof')` builds the env without arguments and its step ignores
+    reward_type (trajopt/envs/utils.py:11-12): rollouts of an MPPI(reward_type='sparse') on it are dense."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    from trajopt.utils import gather_paths_parallel
+    seqs = []
+    for rt in ('dense', 'sparse'):
+        e = get_environment('continual_reacher_7dof')
+        e.reset_model(goal=(0.05, 0.0, 0.1))
+        ag = MPPI(e, H=8, paths_per_cpu=32, kappa=25.0, filter_coefs=[np.ones(7), 0.25, 0.8, 0.0], default_act='mean',
+                  seed=3, reward_type=rt)
+        ag.train_step(niter=2)
+        seqs.append(ag.act_sequence.copy())
+        paths = gather_paths_parallel(e.env_name, ag.sol_state[-1], ag.act_sequence, ag.filter_coefs, 3, None, rt, None,
+                                      1.0, 16, 1)
+        assert not np.isin(paths[0]['rewards'], (-10.0, -100.0, 100.0)).any()
+    assert np.array_equal(seqs[0], seqs[1])
+
+
+def test_worker_streams_leave_the_global_numpy_stream_alone_with_several_workers():
+    """num_cpu == 1 re-seeds the process-global stream (the reference runs that worker in-process,
+    trajopt/utils.py:171-172); with several workers only pool children are re-seeded there."""
+    from trajopt.utils import all_worker_normals
+    np.random.seed(77)
+    want = np.random.RandomState(77).uniform(size=3)
+    a = all_worker_normals(5, 4, 3, 6, 7)
+    assert np.array_equal(np.random.uniform(size=3), want)
+    b = all_worker_normals(5, 12, 1, 6, 7)
+    assert not np.array_equal(np.random.uniform(size=3), want)
+    # overlapping streams: worker i starts at seed + i * paths_per_cpu, same legacy generator either way
+    assert np.array_equal(a[:4], b[:4]) and np.array_equal(a[4:8], all_worker_normals(9, 4, 1, 6, 7))
 
 
 def test_pickled_agent_resolves_through_the_trajopt_names(tmp_path):

@@ -145,3 +145,80 @@ def test_fp32_tolerance_statement(dm):
     assert (e > 1e-4).mean() < 2e-3, (e > 1e-4).mean()
     assert (np.abs(R32 - R64) / np.abs(R64)).max() < 1e-5
     assert int(np.argmax(R32)) == int(np.argmax(R64))
+
+
+def test_captured_graphs_follow_parameter_changes(dm):
+    """plan / set_params / iterate / plan: each captured graph (one iteration, whole planning step) must be
+    rebuilt after a setter changed what it carries, whichever of the two was replayed in between.  The
+    comparison handle launches every kernel by itself (profiling switches graph replay off)."""
+    K, H = 256, 8
+
+    def run(graphs):
+        p = _p(dm, K, H, default_act="mean")
+        p.profile(not graphs)
+        p.set_start_state(np.full(7, -0.1), np.zeros(7), np.array([0.05, 0.0, 0.1]), 0)
+        p.set_base_actions(np.zeros((H, 7)))
+        p.plan(7, 2, 1)                       # captures the step graph with kappa = 25, dense reward
+        p.set_params(3.0, 0.9, "sparse")
+        p.generate_noise(99)
+        p.iterate(1)                          # rebuilds the iteration graph only
+        mid = p.act_sequence()
+        p.plan(7, 2, 1)                       # must not replay the step graph captured with the old parameters
+        p.synchronize()
+        out = (mid, p.act_sequence(), p.returns(), p.read_log())
+        p.close()
+        return out
+    g, k = run(True), run(False)
+    assert np.array_equal(g[0], k[0]) and np.array_equal(g[1], k[1]) and np.array_equal(g[2], k[2])
+    assert g[3]["total"] == k[3]["total"] == 2
+    assert np.array_equal(g[3]["qpos"], k[3]["qpos"]) and np.array_equal(g[3]["reward"], k[3]["reward"])
+
+
+def test_status_reports_non_finite_returns(dm):
+    """A NaN start state (or an action that overflows fp32) must set MPPI_STATUS_NONFINITE; the library is
+    built with -ffinite-math-only, under which a naive test may be folded away."""
+    K, H = 128, 4
+    for dtype in ("f32", "f64"):
+        p = _p(dm, K, H, dtype)
+        q = np.zeros(7)
+        p.set_start_state(q, np.zeros(7), np.zeros(3), 0)
+        p.set_base_actions(np.zeros((H, 7)))
+        p.generate_noise(1)
+        p.rollout()
+        assert p.status() == 0 and np.isfinite(p.returns()).all()
+        q[3] = np.nan
+        p.set_start_state(q, np.zeros(7), np.zeros(3), 0)
+        p.rollout()
+        assert p.status() & 1, dtype
+        assert not np.isfinite(p.returns()).any()
+        p.close()
+    # a start velocity that overflows fp32 inside the step
+    p = _p(dm, K, H, "f32")
+    p.set_start_state(np.zeros(7), np.full(7, 3e38), np.zeros(3), 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.generate_noise(1)
+    p.rollout()
+    assert p.status() & 1
+    p.close()
+
+
+def test_status_reports_a_capped_active_set_solve(dm, oracle_sim):
+    """With the default cap (12 sweeps) no solve of this workload is cut short; with a cap of 2 the substeps
+    that need a third sweep are, and MPPI_STATUS_SWEEP_CAP says so."""
+    K, H = 2048, 32
+    raw = ref_mppi.raw_normals(5, K, H, 7)
+    q0 = np.array([0.3, 1.2, 1.6, -0.1, 1.4, -0.05, 1.45])       # close to several limits
+    got = {}
+    for cap in (0, 2):
+        p = _p(dm, K, H, "f32", sweep_cap=cap)
+        p.set_start_state(q0, np.zeros(7), np.zeros(3), 0)
+        p.set_base_actions(np.zeros((H, 7)))
+        p.upload_noise(raw)
+        p.rollout()
+        got[cap] = (p.status(), p.returns())
+        p.close()
+    assert got[0][0] == 0
+    assert got[2][0] & 2          # (forces of a solve that was cut short may also drive a sample to overflow: bit 0)
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)
+    R_o = oracle_sim.rollout(q0, np.zeros(7), np.zeros(3), 0, eps)
+    assert np.abs(got[0][1] - R_o).max() / np.abs(R_o).max() < 1e-4

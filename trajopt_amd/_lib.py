@@ -38,7 +38,7 @@ class ModelDescC(C.Structure):
 class PlannerCfgC(C.Structure):
     _fields_ = [
         ("K", _i32), ("H", _i32), ("dtype", _i32), ("device", _i32), ("reward_type", _i32),
-        ("default_act", _i32), ("k_offset", _i32), ("dump", _i32), ("P", _i32), ("reserved", _i32),
+        ("default_act", _i32), ("k_offset", _i32), ("dump", _i32), ("P", _i32), ("sweep_cap", _i32),
         ("kappa", _d), ("gamma", _d),
         ("sigma", _d * MAXV), ("beta", _d * 3), ("mean", _d * MAXV),
     ]

@@ -17,7 +17,8 @@ Two keyword arguments are additions with behaviour-preserving defaults:
 import numpy as np
 
 from ..device import DeviceModel, DevicePlanner, update_from_returns
-from ..utils import ReplayBuffer, Tuple, all_worker_normals, gather_paths_parallel, score_trajectory  # noqa: F401
+from ..utils import (ReplayBuffer, Tuple, all_worker_normals, gather_paths_parallel, rollout_objective,  # noqa: F401
+                     score_trajectory)
 from .trajopt_base import Trajectory
 
 _KERNEL_ENVS = {'reacher_7dof': 'reacher_7dof', 'continual_reacher_7dof': 'reacher_7dof'}
@@ -79,7 +80,6 @@ class MPPI(Trajectory):
         d = dict(self.__dict__)
         d.pop('_planner', None)
         d.pop('_planner_key', None)
-        d.pop('_critic_on', None)
         return d
 
     def __setstate__(self, d):
@@ -103,7 +103,7 @@ class MPPI(Trajectory):
                                           gamma=self.gamma, sigma=sig, betas=(b0, b1, b2), mean=self.mean,
                                           default_act=self.default_act, dtype=self.dtype)
             self._planner_key = key
-        rt = self.reward_type if self.reward_type in ('sparse', 'tracking', 'cooling') else 'dense'
+        rt, _ = rollout_objective(self.env.env_name, self.reward_type, self.reference)
         self._planner.set_params(self.kappa, self.gamma, rt)
         return self._planner
 
@@ -154,20 +154,19 @@ class MPPI(Trajectory):
     def _plan_on_device(self, seed, niter, critic_dim=0, critic_weights=None):
         s = self.sol_state[-1]
         H = self.H
-        tracked = self.reward_type in ('tracking', 'cooling')
+        rt, reference = rollout_objective(self.env.env_name, self.reward_type, self.reference)
+        tracked = rt in ('tracking', 'cooling')
         if tracked:
-            if self.reference is None:
+            if reference is None:
                 raise TypeError("'NoneType' object is not subscriptable")
-            if int(s['timestep']) + H >= len(self.reference):
+            if int(s['timestep']) + H >= len(reference):
                 raise IndexError("index %d is out of bounds for axis 0 with size %d"
-                                 % (int(s['timestep']) + H, len(self.reference)))
+                                 % (int(s['timestep']) + H, len(reference)))
         p = self._device_planner()
         p.set_start_state(s['qp'], s['qv'], s['target_pos'], s['timestep'])
-        p.set_reference(self.reference if tracked else None, self.env.alpha)
+        p.set_reference(reference if tracked else None, self.env.alpha)
         p.set_base_actions(self.act_sequence)
-        if critic_dim or getattr(self, '_critic_on', False):
-            p.set_critic(critic_dim, critic_weights)
-            self._critic_on = bool(critic_dim)
+        p.set_critic(critic_dim, critic_weights)         # a no-op while dim and weights stay what they were
         if self.noise == 'philox':
             p.generate_noise(seed)
         else:

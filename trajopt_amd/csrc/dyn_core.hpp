@@ -284,6 +284,9 @@ template <class T, class MD> struct Step {
     // included, starts active when it next appears.
     struct Active {
         T idle[NV + 1];
+        // most sweeps the iteration may take (uniform over a wave); a solve that stops there with the set
+        // still moving reports cap + 1 sweeps.  reset() keeps it.
+        int cap = 12;
         MPPI_HD void reset() { static_for<NV + 1>([&](auto Ic) { idle[Ic] = T(0); }); }
     };
 
@@ -506,7 +509,8 @@ template <class T, class MD> struct Step {
                         right_hand_side();
                         chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
                         changed = settle();
-                    } while (wave_any(changed) && sweeps < 12);
+                    } while (wave_any(changed) && sweeps < act.cap);
+                    if (MPPI_UNLIKELY(wave_any(changed))) sweeps = act.cap + 1;    // gave up: the forces belong to the last set tried
                 }
             };
             if (MPPI_UNLIKELY(wave_any(r.Dc > T(0)))) sweep_all(std::true_type{});

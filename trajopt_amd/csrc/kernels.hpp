@@ -140,9 +140,19 @@ __global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_o
 // ------------------------------------------------------------------------------------------
 // rollout
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool nonfinite(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
+// The library is built with -ffinite-math-only: the compiler may assume that no floating-point value is NaN or
+// infinity and fold a test for them away, a test on the bit pattern included (it recognises the idiom).  The
+// bits are therefore passed through an empty asm statement as an integer, after which nothing is known about
+// them.
+__device__ __forceinline__ bool nonfinite(float x) {
+    unsigned int u = __float_as_uint(x);
+    asm volatile("" : "+v"(u));
+    return (u & 0x7f800000u) == 0x7f800000u;
+}
 __device__ __forceinline__ bool nonfinite(double x) {
-    return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+    unsigned int hi = (unsigned int)((unsigned long long)__double_as_longlong(x) >> 32);
+    asm volatile("" : "+v"(hi));
+    return (hi & 0x7ff00000u) == 0x7ff00000u;
 }
 
 // LEAN: the planning configuration (dense reward, noise-relative samples, nothing dumped, no reference, no
@@ -153,7 +163,7 @@ __global__ void __launch_bounds__(64)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
                const double* __restrict__ ref, int K, int H, int reward_type_, double gamma, int explicit_act_,
                T* __restrict__ R, T* __restrict__ obs_, T* __restrict__ rew_, int* __restrict__ status,
-               T* __restrict__ fobs_, int* __restrict__ next_step) {
+               T* __restrict__ fobs_, int* __restrict__ next_step, int sweep_cap) {
     constexpr int NV = MD::NV, NQ = MD::NQ;
     const int reward_type = LEAN ? int(REWARD_DENSE) : reward_type_;
     const int explicit_act = LEAN ? 0 : explicit_act_;
@@ -184,6 +194,8 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     T ret = T(0), g = T(1);
     typename Step<T, MD>::Active act_rows;
     act_rows.reset();
+    act_rows.cap = sweep_cap;
+    int most_sweeps = 0;
     // the next step's noise and base action are fetched one step ahead: they do not depend on the
     // state, and a lone wave has nobody to hide a load's latency behind
     T a[NV];
@@ -206,8 +218,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
             rr[0] = T(ref[3 * idx]); rr[1] = T(ref[3 * idx + 1]); rr[2] = T(ref[3 * idx + 2]);
         }
         Vec3<T> hand;
-        int ms = 0;
-        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_rows, ms);
+        const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_rows, most_sweeps);
         // with a terminal-value critic the last reward is replaced by the critic's value (added by critic_kernel)
         if (!(fobs && t == H - 1)) ret += g * r;
         g *= gm;
@@ -229,7 +240,8 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         }
     }
     R[k] = ret;
-    if (nonfinite(ret)) atomicOr(status, 1);
+    if (nonfinite(ret)) atomicOr(status, MPPI_STATUS_NONFINITE);
+    if (most_sweeps > sweep_cap) atomicOr(status, MPPI_STATUS_SWEEP_CAP);
 }
 
 // one fp64 env.step of the real environment; io: in [q(nq) v(nv) target(3) act(nv) alpha refrow(3)],
@@ -534,6 +546,7 @@ struct RolloutArgs {
     int K, H, P, reward_type; double gamma; int explicit_act;
     bool lean;      // dense reward, noise-relative samples, no dumps, no reference, no critic
     void* R; void* obs; void* rew; int* status; void* fobs; int* next_step;
+    int sweep_cap;  // most sweeps of the active-set iteration per substep
 };
 
 struct ModelOps {
@@ -615,13 +628,13 @@ template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArg
     const dim3 grid((a.K + 63) / 64, a.P), block(64);      // one wave per block: waves spread over CUs and XCDs
     if (dtype == MPPI_F32 && a.lean)
         hipLaunchKernelGGL((rollout_kernel<float, MD, true>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step);
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step, a.sweep_cap);
     else if (dtype == MPPI_F32)
         hipLaunchKernelGGL((rollout_kernel<float, MD, false>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step);
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step, a.sweep_cap);
     else
         hipLaunchKernelGGL((rollout_kernel<double, MD, false>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs, a.next_step);
+                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs, a.next_step, a.sweep_cap);
     return hipGetLastError();
 }
 template <class MD>

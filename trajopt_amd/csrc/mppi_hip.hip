@@ -78,6 +78,15 @@ __global__ void merge_kernel(const double* __restrict__ gathered, int nranks, in
     if (blockIdx.x == 0 && threadIdx.x == 0) { result[0] = gmax; result[1] = gidx; }
 }
 
+// alpha and the reference length of every planner of a handle (the rest of the device state is left alone: it
+// may be ahead of the host's copy after device-resident steps)
+__global__ void set_reference_fields_kernel(DevState* __restrict__ st, int P, double alpha, int ref_len) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < P; b += gridDim.x * blockDim.x) {
+        st[b].alpha = alpha;
+        st[b].ref_len = ref_len;
+    }
+}
+
 // tmp[t] = src[t+1], tail = previous last row (repeat) or mean
 __global__ void shift_kernel(const double* __restrict__ src, int H, int M, int tail_mode, const double* __restrict__ mean,
                              double* __restrict__ dst) {
@@ -241,9 +250,14 @@ struct mppi_planner {
     uint64_t noise_ahead_seed;   // ... drawn with this seed
     int explicit_act;
     FilterCoefs fc;
-    hipGraphExec_t graph;
-    bool graph_valid;
+    // Captured graphs carry kernel arguments (kappa, gamma, reward type, kernel variant, buffer addresses, critic).
+    // Every setter that changes one of them bumps cfg_gen; a graph is replayed only while the generation it was
+    // captured at is still the current one, each graph on its own.
+    uint64_t cfg_gen;
+    hipGraphExec_t graph;           // one iteration: rollouts -> update
+    uint64_t graph_gen;             // 0: never captured
     hipGraphExec_t step_graph;      // whole planning step: noise -> niter x (rollout, update) -> advance
+    uint64_t step_graph_gen;
     int step_graph_niter;
     uint64_t step_graph_seed;
     bool profiling;
@@ -253,55 +267,10 @@ struct mppi_planner {
 
 static hipStream_t pick(mppi_planner* p, void* s) { return s ? (hipStream_t)s : p->stream; }
 
-extern "C" {
+extern "C" void mppi_planner_destroy(mppi_planner* p);
 
-int mppi_version(void) { return MPPI_ABI_VERSION; }
-const char* mppi_last_error(void) { return g_err.c_str(); }
-
-int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) {
-    if (!desc || !out) return fail(-1, "null argument");
-    std::string why = "unknown model name";
-    for (const ModelOps* op : g_ops) {
-        const ModelOps& o = *op;
-        if (std::strncmp(desc->name, o.name, sizeof(desc->name)) != 0) continue;
-        if (!o.matches(desc, why)) return fail(-3, std::string("model '") + o.name + "': " + why);
-        mppi_model* m = new mppi_model();
-        m->ops = &o;
-        m->desc = *desc;
-        for (auto& x : m->d_io) x = nullptr;
-        *out = m;
-        return 0;
-    }
-    return fail(-3, std::string("no kernel compiled for model '") + std::string(desc->name, strnlen(desc->name, 64)) + "'");
-}
-
-void mppi_model_destroy(mppi_model* m) {
-    if (!m) return;
-    for (int d = 0; d < 16; d++)
-        if (m->d_io[d]) { (void)hipSetDevice(d); (void)hipFree(m->d_io[d]); }
-    delete m;
-}
-
-int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_planner** out) {
-    if (!m || !cfg || !out) return fail(-1, "null argument");
-    if (cfg->K < 1 || cfg->H < 1) return fail(-1, "K and H must be positive");
-    if (cfg->dtype != MPPI_F32 && cfg->dtype != MPPI_F64) return fail(-1, "dtype must be MPPI_F32 or MPPI_F64");
-    HIP_OK(hipSetDevice(cfg->device));
-    {   // set-up time is when the no-allocation update's workspace address is looked up for this device
-        double* ws;
-        const int rc = noalloc_scratch(cfg->device, &ws);
-        if (rc) return rc;
-    }
-    mppi_planner* p = new mppi_planner();
-    std::memset(p, 0, sizeof(*p));
-    p->model = m;
-    p->cfg = *cfg;
-    p->nv = m->ops->nv;
-    p->nq = m->ops->nq;
-    p->HM = cfg->H * p->nv;
-    p->P = cfg->P > 1 ? cfg->P : 1;
-    p->cfg.P = p->P;
-    p->esz = cfg->dtype == MPPI_F32 ? 4 : 8;
+static int planner_allocate(mppi_planner* p) {
+    const mppi_planner_cfg* cfg = &p->cfg;
     const size_t P = p->P;
     const size_t K = cfg->K * P, HM = p->HM * P, OD = p->nq + p->nv + 6;   // sizes over all planners
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -337,9 +306,71 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     HIP_OK(hipMemcpy(p->d_base, base.data(), HM * 8, hipMemcpyHostToDevice));
     for (int j = 0; j < MPPI_MAXV; j++) p->fc.sigma[j] = cfg->sigma[j];
     p->fc.b0 = cfg->beta[0]; p->fc.b1 = cfg->beta[1]; p->fc.b2 = cfg->beta[2];
+    return 0;
+}
+
+extern "C" {
+
+int mppi_version(void) { return MPPI_ABI_VERSION; }
+const char* mppi_last_error(void) { return g_err.c_str(); }
+
+int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) {
+    if (!desc || !out) return fail(-1, "null argument");
+    std::string why = "unknown model name";
+    for (const ModelOps* op : g_ops) {
+        const ModelOps& o = *op;
+        if (std::strncmp(desc->name, o.name, sizeof(desc->name)) != 0) continue;
+        if (!o.matches(desc, why)) return fail(-3, std::string("model '") + o.name + "': " + why);
+        mppi_model* m = new mppi_model();
+        m->ops = &o;
+        m->desc = *desc;
+        for (auto& x : m->d_io) x = nullptr;
+        *out = m;
+        return 0;
+    }
+    return fail(-3, std::string("no kernel compiled for model '") + std::string(desc->name, strnlen(desc->name, 64)) + "'");
+}
+
+void mppi_model_destroy(mppi_model* m) {
+    if (!m) return;
+    for (int d = 0; d < 16; d++)
+        if (m->d_io[d]) { (void)hipSetDevice(d); (void)hipFree(m->d_io[d]); }
+    delete m;
+}
+
+int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_planner** out) {
+    if (!m || !cfg || !out) return fail(-1, "null argument");
+    if (cfg->K < 1 || cfg->H < 1) return fail(-1, "K and H must be positive");
+    if (cfg->dtype != MPPI_F32 && cfg->dtype != MPPI_F64) return fail(-1, "dtype must be MPPI_F32 or MPPI_F64");
+    if (cfg->sweep_cap < 0) return fail(-1, "sweep_cap must not be negative");
+    HIP_OK(hipSetDevice(cfg->device));
+    {   // set-up time is when the no-allocation update's workspace address is looked up for this device
+        double* ws;
+        const int rc = noalloc_scratch(cfg->device, &ws);
+        if (rc) return rc;
+    }
+    mppi_planner* p = new mppi_planner();
+    std::memset(p, 0, sizeof(*p));
+    p->model = m;
+    p->cfg = *cfg;
+    p->nv = m->ops->nv;
+    p->nq = m->ops->nq;
+    p->HM = cfg->H * p->nv;
+    p->P = cfg->P > 1 ? cfg->P : 1;
+    p->cfg.P = p->P;
+    if (p->cfg.sweep_cap == 0) p->cfg.sweep_cap = 12;
+    p->esz = cfg->dtype == MPPI_F32 ? 4 : 8;
+    p->cfg_gen = 1;
     p->prof_events = new std::vector<hipEvent_t>();
-    p->h_state = new std::vector<DevState>(P);
-    std::memset(p->h_state->data(), 0, sizeof(DevState) * P);
+    p->h_state = new std::vector<DevState>(p->P);
+    std::memset(p->h_state->data(), 0, sizeof(DevState) * p->P);
+    // any failure below releases what was allocated before it
+    const int rc = planner_allocate(p);
+    if (rc) {
+        const std::string msg = g_err;
+        mppi_planner_destroy(p);
+        return fail(rc, msg);
+    }
     *out = p;
     return 0;
 }
@@ -347,8 +378,8 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
 void mppi_planner_destroy(mppi_planner* p) {
     if (!p) return;
     (void)hipSetDevice(p->cfg.device);
-    (void)hipStreamSynchronize(p->stream);
-    for (hipEvent_t e : *p->prof_events) (void)hipEventDestroy(e);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->prof_events) for (hipEvent_t e : *p->prof_events) (void)hipEventDestroy(e);
     delete p->prof_events;
     delete p->h_state;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
@@ -357,7 +388,7 @@ void mppi_planner_destroy(mppi_planner* p) {
                     p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    (void)hipStreamDestroy(p->stream);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
 
@@ -391,23 +422,22 @@ int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alp
     if (!p) return fail(-1, "null argument");
     if (T < 0 || (T > 0 && !ref)) return fail(-1, "bad reference");
     HIP_OK(hipSetDevice(p->cfg.device));
-    HIP_OK(hipStreamSynchronize(p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));      // rollouts in flight may still read the old rows
+    const bool had_ref = (*p->h_state)[0].ref_len > 0;
     if (T > p->ref_cap) {
         if (p->d_ref) HIP_OK(hipFree(p->d_ref));
+        p->d_ref = nullptr; p->ref_cap = 0;
         HIP_OK(hipMalloc(&p->d_ref, (size_t)T * 3 * 8));
         p->ref_cap = T;
-        p->graph_valid = false;
+        p->cfg_gen++;                             // captured launches hold the old address
     }
-    if (T > 0) HIP_OK(hipMemcpy(p->d_ref, ref, (size_t)T * 3 * 8, hipMemcpyHostToDevice));
-    // the device copy of q / v / timestep may be ahead of the mirror (mppi_advance): patch only alpha and ref_len
-    std::vector<DevState> s(p->P);
-    HIP_OK(hipMemcpy(s.data(), p->d_state, sizeof(DevState) * p->P, hipMemcpyDeviceToHost));
-    for (int b = 0; b < p->P; b++) {
-        s[b].alpha = alpha; s[b].ref_len = T;
-        (*p->h_state)[b].alpha = alpha; (*p->h_state)[b].ref_len = T;
-    }
-    p->graph_valid = false;       // a captured rollout may be the kernel variant without a reference
-    HIP_OK(hipMemcpy(p->d_state, s.data(), sizeof(DevState) * p->P, hipMemcpyHostToDevice));
+    if ((T > 0) != had_ref) p->cfg_gen++;         // with and without a reference are different kernel variants
+    if (T > 0) HIP_OK(hipMemcpyAsync(p->d_ref, ref, (size_t)T * 3 * 8, hipMemcpyHostToDevice, p->stream));
+    // alpha and the length are fields of the device-resident state, which captured launches read at run time
+    for (int b = 0; b < p->P; b++) { (*p->h_state)[b].alpha = alpha; (*p->h_state)[b].ref_len = T; }
+    hipLaunchKernelGGL(set_reference_fields_kernel, dim3((p->P + 255) / 256), dim3(256), 0, p->stream, p->d_state, p->P, alpha, (int)T);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(p->stream));      // the caller may reuse its buffer
     return 0;
 }
 
@@ -416,8 +446,11 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
-    p->graph_valid = false;
-    if (dim == 0) { p->critic_dim = 0; return 0; }
+    if (dim == 0) {
+        if (p->critic_dim != 0) p->cfg_gen++;
+        p->critic_dim = 0;
+        return 0;
+    }
     if (dim != 14 && dim != 15 && dim != 17 && dim != 3 && dim != 6) return fail(-1, "critic input dim must be 14, 15, 17, 3 or 6");
     if (p->nv != 7) return fail(-1, "critic input slices are defined for the 20-dim reacher observation");
     if (inner != CRITIC_INNER) return fail(-1, "only the 128-wide critic has a compiled kernel");
@@ -435,6 +468,7 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
     if (!p->d_critic) HIP_OK(hipMalloc(&p->d_critic, CRITIC_W_FLOATS * 4));
     if (!p->d_fobs) HIP_OK(hipMalloc(&p->d_fobs, (size_t)p->cfg.K * p->P * (p->nq + p->nv + 6) * p->esz));
     HIP_OK(hipMemcpy(p->d_critic, w.data(), CRITIC_W_FLOATS * 4, hipMemcpyHostToDevice));
+    if (p->critic_dim != dim) p->cfg_gen++;       // the weights are read at run time; the input slice is an argument
     p->critic_dim = dim;
     return 0;
 }
@@ -442,8 +476,8 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
 int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_type) {
     if (!p) return fail(-1, "null argument");
     if (reward_type < 0 || reward_type > 3) return fail(-1, "bad reward_type");
+    if (p->cfg.kappa != kappa || p->cfg.gamma != gamma || p->cfg.reward_type != reward_type) p->cfg_gen++;
     p->cfg.kappa = kappa; p->cfg.gamma = gamma; p->cfg.reward_type = reward_type;
-    p->graph_valid = false;
     return 0;
 }
 
@@ -542,6 +576,7 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
     a.R = p->d_R; a.obs = p->d_obs; a.rew = p->d_rew; a.status = p->d_status;
     a.fobs = p->critic_dim ? p->d_fobs : nullptr;
     a.next_step = p->d_next_step;
+    a.sweep_cap = p->cfg.sweep_cap;
     bool has_ref = false;
     for (int b = 0; b < p->P; b++) has_ref |= (*p->h_state)[b].ref_len > 0;
     a.lean = a.reward_type == REWARD_DENSE && !a.explicit_act && !a.obs && !a.rew && !a.fobs && !has_ref;
@@ -607,6 +642,7 @@ int mppi_merge(mppi_planner* p, const void* gathered, int32_t nranks, void* stre
 
 static int build_graph(mppi_planner* p) {
     if (p->graph) { HIP_OK(hipGraphExecDestroy(p->graph)); p->graph = nullptr; }
+    p->graph_gen = 0;
     hipGraph_t g;
     HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
     int rc = launch_rollout_only(p, p->stream);
@@ -616,7 +652,7 @@ static int build_graph(mppi_planner* p) {
     HIP_OK(e);
     HIP_OK(hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0));
     HIP_OK(hipGraphDestroy(g));
-    p->graph_valid = true;
+    p->graph_gen = p->cfg_gen;
     return 0;
 }
 
@@ -627,7 +663,7 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
     hipStream_t s = pick(p, stream);
     static const bool use_graph = [] { const char* e = getenv("MPPI_GRAPH"); return !(e && e[0] == '0'); }();
     if (use_graph && !p->cfg.dump && !p->profiling) {
-        if (!p->graph_valid) { int rc = build_graph(p); if (rc) return rc; }
+        if (p->graph_gen != p->cfg_gen) { int rc = build_graph(p); if (rc) return rc; }
         for (int i = 0; i < niter; i++) HIP_OK(hipGraphLaunch(p->graph, s));
         return 0;
     }
@@ -685,8 +721,9 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
             if (rc) return rc;
         }
     } else {
-        if (!p->step_graph || !p->graph_valid || p->step_graph_niter != niter || p->step_graph_seed != seed) {
+        if (!p->step_graph || p->step_graph_gen != p->cfg_gen || p->step_graph_niter != niter || p->step_graph_seed != seed) {
             if (p->step_graph) { HIP_OK(hipGraphExecDestroy(p->step_graph)); p->step_graph = nullptr; }
+            p->step_graph_gen = 0;
             hipGraph_t g;
             HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
             int rc = ahead ? 0 : enqueue_plan_noise(p, seed, p->stream);
@@ -696,9 +733,9 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
             HIP_OK(e);
             HIP_OK(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
             HIP_OK(hipGraphDestroy(g));
+            p->step_graph_gen = p->cfg_gen;
             p->step_graph_niter = niter;
             p->step_graph_seed = seed;
-            if (!p->graph_valid) { const int rc2 = build_graph(p); if (rc2) return rc2; }    // shares the validity flag
         }
         if (ahead && !have_noise) { const int rc = enqueue_plan_noise(p, seed, s); if (rc) return rc; }
         for (int i = 0; i < nsteps; i++) HIP_OK(hipGraphLaunch(p->step_graph, s));
@@ -894,16 +931,18 @@ int mppi_update_from_returns(int32_t device, const double* act, const double* R,
                              double* act_seq_out) {
     if (!act || !R || !act_seq_out || K < 1 || HM < 1) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(device));
-    double *d_act = nullptr, *d_R = nullptr, *d_out = nullptr;
-    HIP_OK(hipMalloc(&d_act, (size_t)K * HM * 8));
-    HIP_OK(hipMalloc(&d_R, (size_t)K * 8));
-    HIP_OK(hipMalloc(&d_out, (size_t)HM * 8));
-    HIP_OK(hipMemcpy(d_act, act, (size_t)K * HM * 8, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_R, R, (size_t)K * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(update_direct_kernel, dim3(HM), dim3(256), 0, 0, d_act, d_R, K, (int)HM, kappa, d_out);
+    struct Owned {            // released on every way out
+        double* p = nullptr;
+        ~Owned() { if (p) (void)hipFree(p); }
+    } d_act, d_R, d_out;
+    HIP_OK(hipMalloc(&d_act.p, (size_t)K * HM * 8));
+    HIP_OK(hipMalloc(&d_R.p, (size_t)K * 8));
+    HIP_OK(hipMalloc(&d_out.p, (size_t)HM * 8));
+    HIP_OK(hipMemcpy(d_act.p, act, (size_t)K * HM * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_R.p, R, (size_t)K * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(update_direct_kernel, dim3(HM), dim3(256), 0, 0, d_act.p, d_R.p, K, (int)HM, kappa, d_out.p);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpy(act_seq_out, d_out, (size_t)HM * 8, hipMemcpyDeviceToHost));
-    HIP_OK(hipFree(d_act)); HIP_OK(hipFree(d_R)); HIP_OK(hipFree(d_out));
+    HIP_OK(hipMemcpy(act_seq_out, d_out.p, (size_t)HM * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -72,7 +72,7 @@ class DevicePlanner:
 
     def __init__(self, model: DeviceModel, K, H, kappa=1.0, gamma=1.0, sigma=None, betas=(1.0, 0.0, 0.0),
                  mean=None, default_act="repeat", reward_type="dense", dtype="f32", device=None, k_offset=0,
-                 dump=False, planners=1):
+                 dump=False, planners=1, sweep_cap=0):
         """planners > 1 batches that many independent planners (own start state, base actions, noise
         stream, log) in one handle: every per-planner array gains a leading axis of that size."""
         self.model, self.K, self.H, self.nv, self.nq = model, int(K), int(H), model.nv, model.nq
@@ -86,6 +86,7 @@ class DevicePlanner:
         cfg.default_act = L.TAIL[default_act] if default_act in L.TAIL else L.TAIL["mean"]
         cfg.k_offset, cfg.dump = int(k_offset), int(bool(dump))
         cfg.P = self.P
+        cfg.sweep_cap = int(sweep_cap)
         cfg.kappa, cfg.gamma = float(kappa), float(gamma)
         sigma = np.ones(self.nv) if sigma is None else np.broadcast_to(np.asarray(sigma, float), (self.nv,))
         mean = np.zeros(self.nv) if mean is None else np.asarray(mean, float)
@@ -95,6 +96,8 @@ class DevicePlanner:
             cfg.beta[j] = float(betas[j])
         self.dump = bool(dump)
         self._device = int(cfg.device)
+        self._ref_sent = (None, None)       # what the device holds: calls that would not change it are skipped
+        self._critic_sent = None
         self._h = L._vp()
         L.check(L.lib().mppi_planner_create(model._h, C.byref(cfg), C.byref(self._h)))
 
@@ -127,7 +130,11 @@ class DevicePlanner:
     def set_reference(self, reference, alpha=1.0):
         ref = None if reference is None else L.f64(reference)
         assert ref is None or (ref.ndim == 2 and ref.shape[1] == 3)
+        sent = (None if ref is None else ref.tobytes(), float(alpha))
+        if sent == self._ref_sent:
+            return
         L.check(L.lib().mppi_set_reference(self._h, L.ptr(ref), 0 if ref is None else len(ref), float(alpha)))
+        self._ref_sent = sent
 
     def set_params(self, kappa, gamma, reward_type):
         L.check(L.lib().mppi_set_params(self._h, float(kappa), float(gamma), L.REWARD_TYPES[reward_type]))
@@ -136,13 +143,19 @@ class DevicePlanner:
         """weights = (W1, b1, W2, b2, W3, b3) as float32 arrays in torch's row-major layout, or
         None / dim 0 to remove the critic."""
         if not dim or weights is None:
-            L.check(L.lib().mppi_set_critic(self._h, 0, 0, None, None, None, None, None, 0.0))
+            if self._critic_sent is not None:
+                L.check(L.lib().mppi_set_critic(self._h, 0, 0, None, None, None, None, None, 0.0))
+                self._critic_sent = None
             return
         W1, b1, W2, b2, W3, b3 = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        sent = (int(dim),) + tuple(w.tobytes() for w in (W1, b1, W2, b2, W3, b3))
+        if sent == self._critic_sent:
+            return
         inner = W2.shape[0]
         assert W1.shape == (inner, dim) and W2.shape == (inner, inner) and W3.size == inner and b3.size == 1
         L.check(L.lib().mppi_set_critic(self._h, int(dim), int(inner), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
                                         L.ptr(W3), float(b3.reshape(-1)[0])))
+        self._critic_sent = sent
 
     def upload_noise(self, raw):
         raw = L.f64(raw)

@@ -13,9 +13,10 @@ class ContinualReacher7DOFEnv(Reacher7DOFEnv):
         self._ctor = {}
 
     def _step(self, a):
-        # the observation is taken before a possible target redraw, as in the reference
-        out = self._dense_step(a)
+        # observation and reward are taken before a possible target redraw, the returned infos after it
+        # (trajopt/envs/continual_reacher_env.py:15-23)
+        ob, reward, done, _ = self._dense_step(a)
         due = self.env_timestep > 0 and self.env_timestep % RETARGET_PERIOD == 0
         if due and self.real_step is True:
             self.target_reset()
-        return out
+        return ob, reward, done, self.get_env_infos()

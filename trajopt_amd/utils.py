@@ -108,6 +108,15 @@ def _model_name(env_name):
     raise ValueError("no compiled rollout kernel for environment %r" % (env_name,))
 
 
+def rollout_objective(env_name, reward_type, reference):
+    """(reward_type, reference) the rollout copies of an environment score with.  The continual reacher is
+    built without arguments by `get_environment` and its step ignores `reward_type`
+    (trajopt/envs/utils.py:11-12, trajopt/envs/continual_reacher_env.py:10-17): always dense, no reference."""
+    if env_name == 'continual_reacher_7dof':
+        return 'dense', None
+    return (reward_type if reward_type in ('sparse', 'tracking', 'cooling') else 'dense'), reference
+
+
 def _rollout_planner(env_name, K, H, reward_type, dtype):
     key = (env_name, K, H, dtype)
     p = _PLANNERS.get(key)
@@ -185,6 +194,7 @@ def do_env_rollout(env_name, start_state, act_list, goal, reward_type, reference
         raise ValueError("integer goals select saved PyBullet states of the humanoid env, which has no kernel")
     act = np.ascontiguousarray(np.stack([np.asarray(a, dtype=np.float64) for a in act_list]))
     K, H, _ = act.shape
+    reward_type, reference = rollout_objective(env_name, reward_type, reference)
     _check_reference(reward_type, reference, int(start_state['timestep']), H)
     p = _rollout_planner(env_name, K, H, reward_type, ROLLOUT_DTYPE)
     p.set_start_state(start_state['qp'], start_state['qv'], start_state['target_pos'], start_state['timestep'])
@@ -195,17 +205,24 @@ def do_env_rollout(env_name, start_state, act_list, goal, reward_type, reference
     return _paths_from_device(p, start_state, p.actions(), env_name)
 
 
-def worker_normals(base_seed, n_paths, H, m):
+def worker_normals(base_seed, n_paths, H, m, in_process=True):
     """Raw N(0,1) draws of one reference worker: seed once, then n_paths blocks of (H, m) in
-    order (`generate_paths`, trajopt/utils.py:135-139)."""
-    np.random.seed(base_seed)
-    return np.stack([np.random.normal(loc=0, scale=1.0, size=(H, m)) for _ in range(n_paths)])
+    order (`generate_paths`, trajopt/utils.py:135-139).  in_process: the worker is the calling process itself
+    (the reference's num_cpu == 1 path, trajopt/utils.py:171-172), so the process-global numpy stream is
+    re-seeded and left advanced as there; pool workers re-seed only their own copy of it, which a private
+    generator with the same legacy stream stands for."""
+    if in_process:
+        np.random.seed(base_seed)
+        draw = np.random.normal
+    else:
+        draw = np.random.RandomState(base_seed).normal
+    return np.stack([draw(loc=0, scale=1.0, size=(H, m)) for _ in range(n_paths)])
 
 
 def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m):
     """(K, H, m) draws in global sample order k = worker * paths_per_cpu + j, worker i seeded
     with base_seed + i * paths_per_cpu (trajopt/utils.py:151-152: overlapping streams)."""
-    return np.concatenate([worker_normals(base_seed + i * paths_per_cpu, paths_per_cpu, H, m)
+    return np.concatenate([worker_normals(base_seed + i * paths_per_cpu, paths_per_cpu, H, m, in_process=(num_cpu == 1))
                            for i in range(num_cpu)])
 
 
@@ -230,6 +247,7 @@ def gather_paths_parallel(env_name, start_state, base_act, filter_coefs, base_se
     base_act = np.asarray(base_act, dtype=np.float64)
     H, m = base_act.shape
     K = paths_per_cpu * num_cpu
+    reward_type, reference = rollout_objective(env_name, reward_type, reference)
     _check_reference(reward_type, reference, int(start_state['timestep']), H)
     raw = all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m)
     sigma, b0, b1, b2 = filter_coefs

@@ -122,7 +122,7 @@ template <class T> using Pair = typename PairOf<T>::type;
 template <class T> MPPI_HD Pair<T> make_pair_of(T a, T b) { Pair<T> p = {a, b}; return p; }
 // a pair of which only half H is ever looked at (the other half costs no instruction on the device)
 template <int H, class T> MPPI_HD Pair<T> half_pair(T a) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(MPPI_UNDEF_HALVES)      // (the macro: host builds under MemorySanitizer)
     Pair<T> p;
     p[H] = a;
     return p;
@@ -755,7 +755,7 @@ template <class T, class MD> struct Step {
                 T J[6];
                 if constexpr (MD::jtype[i] == 2) {
                     // J = R I R^T with a full rotation matrix
-                    const T (&R)[9] = rb_of<decltype(Icn)::value>(fr);
+                    const T (&R)[9] = rb_of<i>(fr);       // the matrix of link i (not of the loop counter NV - 1 - i)
                     T RI[3][3];
                     static_for<3>([&](auto Rn) {
                         static_for<3>([&](auto Cn) {

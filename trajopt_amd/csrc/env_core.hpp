@@ -20,9 +20,13 @@ template <class T> struct RewardParams {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// The fp64 substep is kept out of line on the device: inlined into the rollout loop it is
-// miscompiled by ROCm 7.2's hipcc (wrong values that change from build to build); as a
-// function of its own it matches the fp64 oracle to rounding.  fp32 stays inline.
+// fp64 substep of the wide models as a function of its own.  Inlined into the rollout loop, the fp64 kernel of an
+// 18-DoF model needs 256 VGPRs + 256 AGPRs + about 700 bytes of scratch + 90 spilled SGPRs, and ROCm 7.2's hipcc
+// then emits wrong code for it: every IR-level pass leaves it right (-opt-bisect-limit), the result flips inside
+// that one kernel's machine passes, back and forth with which of them run; the host build of the same source is
+// clean under MemorySanitizer / UBSan / ASan (tools/host_sanitize.sh, tools/f64_*.sh).  Out of line the substep
+// has a frame of its own and matches the fp64 oracle to rounding.  The 7-DoF arm fits and stays inline (right
+// under every flag combination tried, and its real-env step is a quarter faster that way); fp32 is always inline.
 template <class MD>
 __device__ __noinline__ void substep_outofline(double (&q)[MD::NQ], double (&qd)[MD::NV], const double (&act)[MD::NV],
                                                bool want_hand, typename Step<double, MD>::Out& o,
@@ -58,7 +62,7 @@ template <class T, class MD> struct Env {
         typename S::Out o;
         o.hand = {{T(0), T(0), T(0)}};
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (std::is_same<T, double>::value) {
+        if constexpr (std::is_same<T, double>::value && (MD::NV > 8)) {
 #pragma nounroll
             for (int s = 0; s < MD::FRAME_SKIP; s++) {
                 int sw;
@@ -66,8 +70,7 @@ template <class T, class MD> struct Env {
                 max_sweeps = sw > max_sweeps ? sw : max_sweeps;
             }
         } else {
-            // fp32: the substeps are laid out one after the other (no loop branch, the end-effector site only in
-            // the last one)
+            // the substeps are laid out one after the other (no loop branch, the end-effector site only in the last one)
             static_for<MD::FRAME_SKIP>([&](auto Sc) {
                 int sw;
                 S::substep(q, qd, act, Sc == MD::FRAME_SKIP - 1, o, rows, sw);

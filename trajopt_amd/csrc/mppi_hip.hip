@@ -201,10 +201,16 @@ static int noalloc_scratch(int device, double** out) {
 }
 
 // one table per compiled model (model_ops.hip)
+#if defined(MPPI_ONLY_MODEL)          // one-model builds for kernel experiments (never the shipped library)
+#define MPPI_OPS_CAT2(a, b) a##b
+#define MPPI_OPS_CAT(a, b) MPPI_OPS_CAT2(a, b)
+extern const ModelOps MPPI_OPS_CAT(mppi_ops_, MPPI_ONLY_MODEL);
+static const ModelOps* const g_ops[] = {&MPPI_OPS_CAT(mppi_ops_, MPPI_ONLY_MODEL)};
+#elif defined(MPPI_ONLY_REACHER)    // quick builds for kernel experiments (make quick)
 extern const ModelOps mppi_ops_Reacher7Dof;
-#if defined(MPPI_ONLY_REACHER)      // quick builds for kernel experiments (make quick)
 static const ModelOps* const g_ops[] = {&mppi_ops_Reacher7Dof};
 #else
+extern const ModelOps mppi_ops_Reacher7Dof;
 extern const ModelOps mppi_ops_Reacher7DofFree, mppi_ops_Tree18Dof, mppi_ops_Tree18DofQuat, mppi_ops_Tree18DofRk4;
 static const ModelOps* const g_ops[] = {&mppi_ops_Reacher7Dof, &mppi_ops_Reacher7DofFree, &mppi_ops_Tree18Dof,
                                         &mppi_ops_Tree18DofQuat, &mppi_ops_Tree18DofRk4};

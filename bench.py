@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
-"""Headline benchmark: MPPI planning steps on reacher_7dof, K = 4096 samples per GPU, H = 64.
+"""Headline benchmark: MPPI planning steps on reacher_7dof, H = 64: K = 4096 samples on one GPU; with N > 1 ranks
+one planner of K = 65536 samples sharded over the N GPUs (strong scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one planning step of `MPPI.train_step(niter=1)` with everything resident on the
 device and enqueued on one stream without host synchronisation: Philox noise + filter,
-K x H rollouts with fused reward / discounted return, max / weights / weighted action sum,
-(N > 1: one RCCL all-gather of the per-rank statistics), merge into act_sequence, the single
-fp64 step of the real environment from the planner's own state, and the horizon shift.
-On one GPU a step is one `mppi_plan` call (a hipGraph replay; every 8th step is launched kernel
-by kernel with HIP events around the rollout kernel, which gives roofline.kernel_ms).
-With N ranks each rank rolls out its own K = 4096 shard of a 4096*N-sample planner (weak
-scaling); sample noise is addressed by global index so the result does not depend on N.
+K x H rollouts with fused reward / discounted return, max / weights / weighted action sum
+(N > 1: this shard's statistics, one RCCL all-gather of 3 + H*M doubles per rank made by the library,
+rank-ordered merge), the single fp64 step of the real environment from the planner's own state, and
+the horizon shift.  A step is one `mppi_plan` call, the replay of one captured hipGraph (every 8th
+step is launched piece by piece with HIP events around the rollout kernel: roofline.kernel_ms).
+Sample noise is addressed by global index, so the planner's result does not depend on N.  With N > 1
+rank 0 first times the same K = 65536 planner on its GPU alone; `strong_scaling.efficiency` is
+T(1) / (N * T(N)).
 
 Prints one JSON line (rank 0).  `value` = env steps per second summed over all ranks.
 """
@@ -28,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K_PER_GPU, H, M = 4096, 64, 7
+K_STRONG = 65536                   # the sharded planner of the multi-GPU runs
 KAPPA, GAMMA = 25.0, 1.0
 FILTER = [np.ones(M), 0.25, 0.8, 0.0]
 SEED = 123
@@ -99,6 +102,15 @@ def measured_traffic():
     return None
 
 
+def make_planner(K, k_offset, device):
+    from trajopt_amd.device import DeviceModel, DevicePlanner
+    p = DevicePlanner(DeviceModel.get("reacher_7dof"), K, H, kappa=KAPPA, gamma=GAMMA, sigma=FILTER[0], betas=FILTER[1:],
+                      mean=np.zeros(M), default_act="mean", dtype="f32", device=device, k_offset=k_offset)
+    p.set_start_state(np.zeros(M), np.zeros(M), np.zeros(3), 0)
+    p.set_base_actions(np.zeros((H, M)))
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +118,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    # RCCL prints a version banner on standard output when a communicator is made; the result line must be the only
+    # thing there, so everything else this process (and the libraries in it) prints goes to standard error
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,18 +141,18 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from trajopt_amd.device import DeviceModel, DevicePlanner
+    from trajopt_amd import sharding
 
-    # MPPI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
-    # devices round-robin and are time-sliced by the driver, the exchange goes through host memory: a functional
-    # check whose timings mean nothing); the measured configuration is RCCL ("nccl"), one rank per GPU
+    # MPPI_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+    # devices round-robin; RCCL refuses two ranks on one GPU, so the exchange then goes through torch.distributed and
+    # host memory: a functional check whose timings mean nothing); the measured configuration is RCCL, one rank per GPU
     backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    # MPPI_BENCH_SHARDED=1 exercises the sharded code path (partials, all-gather, merge) on one rank
+    # MPPI_BENCH_SHARDED=1 exercises the sharded code path (statistics, all-gather, merge) on one rank
     sharded = world > 1 or os.environ.get("MPPI_BENCH_SHARDED") == "1"
-    if sharded:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
@@ -143,54 +160,83 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    dm = DeviceModel.get("reacher_7dof")
-    p = DevicePlanner(dm, K_PER_GPU, H, kappa=KAPPA, gamma=GAMMA, sigma=FILTER[0], betas=FILTER[1:],
-                      mean=np.zeros(M), default_act="mean", dtype="f32", device=local_rank,
-                      k_offset=rank * K_PER_GPU)
-    p.set_start_state(np.zeros(M), np.zeros(M), np.zeros(3), 0)
-    p.set_base_actions(np.zeros((H, M)))
+    # One GPU: the headline planner, K = 4096.  Several GPUs: ONE planner of K_STRONG samples sharded over the
+    # ranks (strong scaling: the work per planning step is fixed, each rank rolls out K_STRONG / N of it).
+    K_total = K_PER_GPU if world == 1 else K_STRONG
+    K_local = K_total // world
+    if K_local * world != K_total:
+        raise SystemExit("%d ranks do not divide K = %d" % (world, K_total))
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
-    if sharded:
-        part = p.partials_tensor()
-        gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
 
-    # One GPU: every step is mppi_plan (noise ahead, rollouts, update, real-env step, shift).  It replays one captured
-    # hipGraph per step; on every PROFILE_EVERY-th step it launches the same kernels one by one instead, with HIP
-    # events around the rollout kernel (a graph replay cannot be timed from inside), which is where
-    # roofline.kernel_ms comes from.  Several ranks: the exchange sits between the kernels, so they are launched
-    # one by one on every step, all of them timed.
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # strong scaling is quoted against the same planner on one GPU, timed here on rank 0 while the others wait
+    t1_ms = None
+    if world > 1:
+        if rank == 0:
+            p1 = make_planner(K_total, 0, local_rank)
+            for _ in range(5):
+                p1.plan(SEED, 1, 1, sptr)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                p1.plan(SEED, 1, 1, sptr)
+            torch.cuda.synchronize()
+            t1_ms = 1e3 * (time.perf_counter() - t0) / 50
+            p1.close()
+        barrier()
+
+    p = make_planner(K_local, rank * K_local, local_rank)
+    exchange = "none (single GPU)"
+    torch_exchange = False
+    if sharded:
+        # the exchange lives inside the library: one RCCL all-gather of 3 + H*M doubles per rank, captured with the
+        # kernels in the planning step's hipGraph
+        exchange = "RCCL all-gather inside the library, captured in the step graph"
+        try:
+            if backend != "nccl" and world > 1:
+                raise RuntimeError("rehearsal backend: ranks share GPUs")
+            sharding.init_library_exchange(p, rank, world, device="cuda:%d" % local_rank)
+        except Exception as e:             # noqa: BLE001  (reported in the result line, never silent)
+            torch_exchange = True
+            exchange = "torch.distributed all-gather between library calls (library exchange unavailable: %s)" % (e,)
+            part = p.partials_tensor()
+            gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
+
+    # Every step is one mppi_plan call: noise (drawn ahead in the previous step's advance launch), rollouts, update
+    # (sharded: statistics, all-gather, merge), real-env fp64 step, horizon shift -- a replay of one captured
+    # hipGraph.  On every PROFILE_EVERY-th step the same work is launched piece by piece instead, with HIP events
+    # around the rollout kernel (a graph replay cannot be timed from inside): that is roofline.kernel_ms.
     PROFILE_EVERY = 8
 
     def planning_step(i):
         # everything below is enqueued on one stream; there is no host synchronisation inside a step
-        if not sharded:
+        if not torch_exchange:
             p.profile(timed[0] and i % PROFILE_EVERY == 0)
             p.plan(SEED, 1, 1, sptr)
             return
-        # the Philox noise of this step (key = SEED + timestep, read on the device) was drawn by the previous
-        # step's advance launch, next to the real-env step; the first step draws its own (before the loop)
         p.local_partials(sptr)
         if backend == "nccl":
             dist.all_gather_into_tensor(gathered, part)
         else:
-            dist.all_gather(list(gathered.view(world, -1).unbind(0)), part)
+            stream.synchronize()
+            host = [torch.empty(part.numel(), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(host, part.cpu())
+            gathered.copy_(torch.cat(host))
         p.merge(gathered.data_ptr(), world, sptr)
-        p.advance_noise(SEED, sptr)                  # real env fp64 step with act_sequence[0], log, horizon shift,
-                                                     # and the next step's noise on the idle CUs of the same launch
-
-    def barrier():
-        if sharded:
-            dist.barrier()
-        torch.cuda.synchronize()
+        p.advance_noise(SEED, sptr)
 
     timed = [False]
-    if sharded:
+    if torch_exchange:
         p.generate_noise_step(SEED, sptr)
     for i in range(args.warmup):
         planning_step(i)
     timed[0] = True
-    p.profile(sharded)
+    p.profile(torch_exchange)
     p.profile_read()
     barrier()
     t0 = time.perf_counter()
@@ -200,43 +246,52 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms, launches = p.profile_read()
     p.profile(False)
-    if sharded:
+    if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     if rank == 0:
-        env_steps = world * K_PER_GPU * H * args.steps
+        env_steps = K_total * H * args.steps
         k_ms = kernel_ms / max(launches, 1)
-        flop_launch = flops * K_PER_GPU * H
+        flop_launch = flops * K_local * H
         achieved = flop_launch / (k_ms * 1e-3) / 1e12
-        bytes_launch = K_PER_GPU * H * M * 4 + K_PER_GPU * 4 + H * M * 8
+        bytes_launch = K_local * H * M * 4 + K_local * 4 + H * M * 8
+        ms_step = 1e3 * dt / args.steps
         out = {
             "metric": "env_steps_per_sec", "value": env_steps / dt, "unit": "env_steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
             "planning_steps_per_sec": args.steps / dt,
-            "config": {"workload": "reacher_7dof MPPI planning step, K=%d samples per GPU (%d total), H=%d, niter=1, "
+            "config": {"workload": "reacher_7dof MPPI planning step, K=%d samples (%d per GPU), H=%d, niter=1, "
                                    "dense reward, kappa=25, filter (0.25, 0.8, 0), Philox noise on device, "
-                                   "real-env fp64 step included" % (K_PER_GPU, world * K_PER_GPU, H),
-                       "K_per_gpu": K_PER_GPU, "K_total": world * K_PER_GPU, "H": H, "frame_skip": 2, "niter": 1,
-                       "parallelism": "samples sharded %d-way, one all-gather of %d doubles per rank per step"
-                                      % (world, 3 + H * M) if world > 1 else "single GPU"},
+                                   "real-env fp64 step included" % (K_total, K_local, H),
+                       "K_per_gpu": K_local, "K_total": K_total, "H": H, "frame_skip": 2, "niter": 1,
+                       "parallelism": ("one planner, samples sharded %d-way by global index; per step one all-gather of "
+                                       "%d doubles per rank" % (world, 3 + H * M)) if world > 1 else "single GPU",
+                       "exchange": exchange},
             "roofline": {"bound": "valu", "kernel": "rollout_kernel<float, Reacher7Dof, true>",
                          "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": measured_traffic(),
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": measured_traffic() if K_local == K_PER_GPU else None,
                          "flop_per_env_step": flops, "kernel_ms": k_ms, "launches": launches,
                          "hbm": {"algorithmic_bytes_per_launch": bytes_launch,
                                  "achieved_GBs": bytes_launch / (k_ms * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": bytes_launch / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
         }
+        if t1_ms is not None:
+            # T(1 GPU, K) / (N * T(N GPUs, K)), both measured in this run
+            out["strong_scaling"] = {"K_total": K_total, "one_gpu_ms_per_step": t1_ms, "n_gpu_ms_per_step": ms_step,
+                                     "efficiency": t1_ms / (world * ms_step)}
         if base is not None:
             out["cpu_baseline"] = base
         log = p.read_log(args.steps + args.warmup)
         out["config"]["real_env_steps_logged"] = int(log["total"])
         out["config"]["final_hand_target_distance"] = float(np.linalg.norm(log["hand"][-1] - log["target"][-1]))
-        print(json.dumps(out), flush=True)
-    if sharded:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
         dist.destroy_process_group()
 
 

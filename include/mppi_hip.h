@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define MPPI_MAXV 32
-#define MPPI_ABI_VERSION 4
+#define MPPI_ABI_VERSION 5
 #define MPPI_LOG_CAP 4096
 #define MPPI_NOALLOC_MAX_K 262144   /* most samples mppi_update_from_returns_noalloc accepts */
 
@@ -172,6 +172,17 @@ int mppi_local_partials(mppi_planner* p, void* stream);
 int mppi_partials_ptr(mppi_planner* p, void** device_ptr, size_t* bytes);
 int mppi_merge(mppi_planner* p, const void* gathered_device_ptr, int32_t nranks, void* stream);
 
+/* The same exchange inside the library: after mppi_comm_init, mppi_iterate and mppi_plan run the sharded form by
+ * themselves -- statistics, one RCCL all-gather of 3 + H*M doubles per planner and rank on the planner's stream,
+ * merge -- so that a whole planning step, exchange included, is one captured hipGraph and every rank ends an
+ * iteration with the identical act_sequence.  Rank r must own the samples [r*K, (r+1)*K) (cfg.k_offset = r*K),
+ * and all ranks the same start state, base actions and parameters.  mppi_comm_unique_id makes the 128-byte id on
+ * one rank; the caller hands it to the others (any channel: MPI, torch.distributed, a file) and every rank calls
+ * mppi_comm_init, which is collective.  RCCL is looked up at run time (librccl.so); -7 reports its errors.
+ * Replaces the worker pool's result collection (trajopt/utils.py:157-161). */
+int mppi_comm_unique_id(void* id_out_128, size_t bytes);
+int mppi_comm_init(mppi_planner* p, const void* id_128, size_t bytes, int32_t rank, int32_t nranks);
+
 /* Horizon shift and tail fill of `MPPI.advance_time` (trajopt/algos/mppi.py:85-89);
  * override_seq_HxM may be NULL (use the planner's own sequence). */
 int mppi_shift(mppi_planner* p, const double* override_seq_HxM, void* stream);
@@ -185,7 +196,7 @@ int mppi_advance(mppi_planner* p, void* stream);
 /* nsteps whole planning steps -- the loop `for t: agent.train_step(niter)` of the example scripts
  * (sandbox/examples/reacher_7dof_mppi.py:49-50) -- enqueued as replays of one captured hipGraph:
  * Philox noise keyed by seed + timestep, niter x (rollouts, update), device-resident advance.
- * Nothing returns to the host until mppi_read_log / mppi_read.  On handles of up to 65536 samples the
+ * Nothing returns to the host until mppi_read_log / mppi_read.  On handles of up to 32768 samples the
  * noise of step t+1 is drawn in the advance launch of step t (see mppi_advance_noise); afterwards the
  * noise buffer (MPPI_READ_ACTIONS) therefore belongs to the step that has not been planned yet. */
 int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream);

@@ -30,18 +30,15 @@ def _rank_main(rank, world, port, K, H, M, kappa, out_dir):
     R = rs.randn(K) * 3 - 50
     R[[5, K - 3]] = R.max() + 1.0                       # tie for the maximum: first index must win
     lo, hi = sharding.shard_range(K, rank, world)
-    rmax, amax, num, den = ref_mppi.partials(eps[lo:hi], R[lo:hi], kappa)
+    rmax, amax, num, den = ref_mppi.partials(eps[lo:hi], R[lo:hi], kappa)       # noise-relative, as on the device
     row = np.concatenate([[rmax, lo + amax, den], num.ravel()])
     assert row.size == sharding.partials_size(H, M)
     gathered = sharding.all_gather_partials(torch.from_numpy(row), world).numpy().reshape(world, -1)
-    parts = [(g[0], int(g[1]), g[3:].reshape(H, M), g[2]) for g in gathered]
     base = rs.randn(H, M)
-    gmax = max(p[0] for p in parts)
-    w = [np.exp(kappa * (p[0] - gmax)) for p in parts]
-    den_g = sum(wi * p[3] for wi, p in zip(w, parts))
-    num_g = sum(wi * p[2] for wi, p in zip(w, parts))
-    seq = (base * den_g + num_g) / (den_g + 1e-6)
-    amax_g = min(p[1] for p in parts if p[0] == gmax)
+    seq, _, amax_g = sharding.merge_rows(gathered, base, kappa)      # the product's merge rule
+    # rows in the reference's own terms: sum S * (base + eps) = base * sum S + sum S * eps
+    parts = [(g[0], int(g[1]), base * g[2] + g[3:].reshape(H, M), g[2]) for g in gathered]
+    assert np.allclose(seq, ref_mppi.merge_partials(parts, kappa), rtol=1e-12, atol=1e-13)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), seq=seq, amax=amax_g,
              want=ref_mppi.update(base + eps, R, kappa), want_amax=int(np.argmax(R)))
     dist.destroy_process_group()

@@ -235,6 +235,61 @@ def test_sharded_partials_merge_to_single_rank_result(dev_model):
         assert s.argmax() == full.argmax()
 
 
+def test_merge_kernel_equals_the_host_merge_rule(dev_model):
+    """mppi_merge on gathered shard rows against trajopt_amd.sharding.merge_rows (what the gloo ranks apply)."""
+    import torch
+    from trajopt_amd import sharding
+    K, H, G = 192, 10, 3
+    base = np.random.RandomState(4).randn(H, 7) * 0.2
+    shards = []
+    for r in range(G):
+        s = _planner(dev_model, K // G, H, "f32", k_offset=r * (K // G))
+        s.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, 0.0, 0.1]), 0)
+        s.set_base_actions(base)
+        s.generate_noise(17)
+        s.local_partials()
+        s.synchronize()
+        shards.append(s)
+    rows = np.stack([s.partials() for s in shards])
+    want, rmax, amax = sharding.merge_rows(rows, base, 25.0)
+    gathered = torch.from_numpy(rows).cuda()
+    torch.cuda.synchronize()
+    for s in shards:
+        s.merge(gathered.data_ptr(), G)
+        assert np.abs(s.act_sequence() - want).max() < 1e-13
+        assert s.argmax() == amax and s.rmax() == rmax
+        s.close()
+
+
+def test_in_library_exchange_on_one_rank_equals_the_unsharded_planner(dev_model):
+    """After mppi_comm_init (RCCL, one rank) iterate() and plan() take the sharded route -- statistics,
+    all-gather on the planner's stream, merge -- inside the captured graphs; results must equal the planner that
+    owns all samples, bit for bit (same kernels, same order of sums)."""
+    from trajopt_amd import sharding
+    K, H, steps, niter = 512, 12, 5, 2
+    tgt = np.array([0.05, 0.05, 0.1])
+    a = _planner(dev_model, K, H, "f32")
+    b = _planner(dev_model, K, H, "f32")
+    sharding.init_library_exchange(b, 0, 1)
+    for p in (a, b):
+        p.set_start_state(np.zeros(7), np.zeros(7), tgt, 0)
+        p.set_base_actions(np.zeros((H, 7)))
+        p.generate_noise(3)
+        p.iterate(2)
+    assert np.array_equal(a.act_sequence(), b.act_sequence()) and a.argmax() == b.argmax() and a.rmax() == b.rmax()
+    for p in (a, b):
+        p.plan(91, niter=niter, nsteps=steps)
+    la, lb = a.read_log(), b.read_log()
+    assert la["total"] == lb["total"] == steps
+    for key in ("qpos", "qvel", "hand", "reward", "action"):
+        assert np.array_equal(la[key], lb[key]), key
+    assert np.array_equal(a.act_sequence(), b.act_sequence())
+    from trajopt_amd._lib import MppiError
+    with pytest.raises(MppiError):
+        sharding.init_library_exchange(b, 0, 1)          # one exchange per planner
+    a.close(); b.close()
+
+
 def test_shift_and_tail(dev_model):
     H = 6
     seq = np.random.RandomState(2).randn(H, 7)

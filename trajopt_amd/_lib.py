@@ -75,6 +75,8 @@ _PROTOS = {
     "mppi_local_partials": (C.c_int, [_vp, _vp]),
     "mppi_partials_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "mppi_merge": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "mppi_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
+    "mppi_comm_init": (C.c_int, [_vp, _vp, C.c_size_t, _i32, _i32]),
     "mppi_shift": (C.c_int, [_vp, _vp, _vp]),
     "mppi_read": (C.c_int, [_vp, _i32, _vp, C.c_size_t]),
     "mppi_profile": (C.c_int, [_vp, _i32]),

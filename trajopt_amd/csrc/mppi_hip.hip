@@ -16,6 +16,7 @@
 // Layout in HBM: eps is stored step-major, sample-minor ([H][M][K]) so that the 64 lanes of
 // a wave read 64 consecutive values per (t, j); returns are [K]; act_sequence is [H][M] fp64.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cfloat>
 #include <cmath>
@@ -219,6 +220,49 @@ static const ModelOps* const g_ops[] = {&mppi_ops_Reacher7Dof, &mppi_ops_Reacher
 // ------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// RCCL, bound at run time: the process may already hold the copy PyTorch ships, and planners that are not
+// sharded never need it
+// ------------------------------------------------------------------------------------------
+struct RcclUniqueId { char internal[128]; };
+struct RcclApi {
+    int (*GetUniqueId)(RcclUniqueId*);
+    int (*CommInitRank)(void**, int, RcclUniqueId, int);
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+    int (*CommDestroy)(void*);
+    const char* (*GetErrorString)(int);
+};
+constexpr int RCCL_FLOAT64 = 8;
+static const RcclApi* rccl_api(std::string& why) {
+    static std::mutex mu;
+    static RcclApi api;
+    static bool loaded = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (loaded) return &api;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) { why = "RCCL library not found (librccl.so)"; return nullptr; }
+    api.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, RcclUniqueId, int))dlsym(h, "ncclCommInitRank");
+    api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    api.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    api.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) {
+        why = "RCCL library lacks an expected entry point";
+        return nullptr;
+    }
+    loaded = true;
+    return &api;
+}
+#define RCCL_OK(api, expr)                                                                             \
+    do {                                                                                               \
+        const int r_ = (expr);                                                                         \
+        if (r_ != 0) return fail(-7, std::string(#expr) + ": " + (api)->GetErrorString(r_));           \
+    } while (0)
+
 struct mppi_model {
     const ModelOps* ops;
     mppi_model_desc desc;
@@ -266,6 +310,11 @@ struct mppi_planner {
     uint64_t step_graph_gen;
     int step_graph_niter;
     uint64_t step_graph_seed;
+    // exchange of the shard statistics between the ranks of a sharded planner (mppi_comm_init)
+    void* comm;                     // ncclComm_t, or null: the planner is not sharded
+    int comm_rank, comm_nranks;
+    double* d_gathered;             // [nranks][P][3 + HM]; d_part then points at this rank's row of it (in-place gather)
+    double* d_part_alloc;           // the allocation d_part pointed at before
     bool profiling;
     std::vector<hipEvent_t>* prof_events;   // start/stop pairs around every rollout launch
     std::vector<DevState>* h_state;         // host mirror of the fields the host sets (alpha, ref_len, start state)
@@ -390,8 +439,13 @@ void mppi_planner_destroy(mppi_planner* p) {
     delete p->h_state;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     if (p->step_graph) (void)hipGraphExecDestroy(p->step_graph);
+    if (p->comm) {
+        std::string why;
+        if (const RcclApi* api = rccl_api(why)) (void)api->CommDestroy(p->comm);
+    }
+    if (p->d_gathered) (void)hipFree(p->d_gathered);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R,
-                    p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
+                    p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -610,6 +664,23 @@ static int launch_update_fused(mppi_planner* p, hipStream_t s) {
     return 0;
 }
 
+static int launch_merge(mppi_planner* p, const double* gathered, int nranks, hipStream_t s);
+
+// `MPPI.update` of one iteration: a single launch on a planner that owns all samples; on a sharded planner
+// this shard's statistics, one all-gather of 3 + H*M doubles per planner and rank, and the rank-ordered merge
+// that every rank applies identically.  All of it is stream work and can be captured.
+static int launch_update(mppi_planner* p, hipStream_t s) {
+    if (!p->comm) return launch_update_fused(p, s);
+    int rc = launch_partials(p, s);
+    if (rc) return rc;
+    std::string why;
+    const RcclApi* api = rccl_api(why);
+    if (!api) return fail(-7, why);
+    const size_t row = (size_t)(3 + p->HM) * p->P;
+    RCCL_OK(api, api->AllGather(p->d_part, p->d_gathered, row, RCCL_FLOAT64, p->comm, s));      // in place
+    return launch_merge(p, p->d_gathered, p->comm_nranks, s);
+}
+
 static int launch_merge(mppi_planner* p, const double* gathered, int nranks, hipStream_t s) {
     hipLaunchKernelGGL(merge_kernel, dim3((p->HM + 255) / 256, p->P), dim3(256), 0, s, gathered, nranks, p->HM, p->cfg.kappa,
                        p->d_base, p->d_result);
@@ -652,7 +723,7 @@ static int build_graph(mppi_planner* p) {
     hipGraph_t g;
     HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
     int rc = launch_rollout_only(p, p->stream);
-    if (!rc) rc = launch_update_fused(p, p->stream);
+    if (!rc) rc = launch_update(p, p->stream);
     hipError_t e = hipStreamEndCapture(p->stream, &g);
     if (rc) return rc;
     HIP_OK(e);
@@ -675,7 +746,7 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
     }
     for (int i = 0; i < niter; i++) {
         int rc = launch_rollout_only(p, s);
-        if (!rc) rc = launch_update_fused(p, s);
+        if (!rc) rc = launch_update(p, s);
         if (rc) return rc;
     }
     return 0;
@@ -685,13 +756,13 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
 // The noise of the coming step is drawn in the advance launch of the previous one when the handle is small enough
 // for that launch to have idle CUs (the fp64 step next to it sets the kernel's register budget, which would slow a
 // GPU-filling noise pass down).
-static bool plan_draws_ahead(const mppi_planner* p) { return (long)p->cfg.K * p->P <= 65536; }
+static bool plan_draws_ahead(const mppi_planner* p) { return (long)p->cfg.K * p->P <= 32768; }
 
 // niter x (rollouts, update), then the real-env step; the noise of this step must be in place
 static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStream_t s) {
     for (int i = 0; i < niter; i++) {
         int rc = launch_rollout_only(p, s);
-        if (!rc) rc = launch_update_fused(p, s);
+        if (!rc) rc = launch_update(p, s);
         if (rc) return rc;
     }
     if (plan_draws_ahead(p))
@@ -930,6 +1001,42 @@ int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, do
     double out[4 * MPPI_MAXV + 16];
     HIP_OK(hipMemcpy(out, io + 256, (2 * ns + 7) * 8, hipMemcpyDeviceToHost));
     for (int c = 0; c < 3; c++) hand3_out[c] = out[2 * ns + c];
+    return 0;
+}
+
+int mppi_comm_unique_id(void* id_out, size_t bytes) {
+    if (!id_out || bytes != sizeof(RcclUniqueId)) return fail(-1, "the exchange id is 128 bytes");
+    std::string why;
+    const RcclApi* api = rccl_api(why);
+    if (!api) return fail(-7, why);
+    RCCL_OK(api, api->GetUniqueId((RcclUniqueId*)id_out));
+    return 0;
+}
+
+int mppi_comm_init(mppi_planner* p, const void* id, size_t bytes, int32_t rank, int32_t nranks) {
+    if (!p || !id || bytes != sizeof(RcclUniqueId)) return fail(-1, "bad argument (the exchange id is 128 bytes)");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "rank must lie in [0, nranks)");
+    if (p->comm) return fail(-4, "the planner already has an exchange");
+    std::string why;
+    const RcclApi* api = rccl_api(why);
+    if (!api) return fail(-7, why);
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    RcclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    void* comm = nullptr;
+    RCCL_OK(api, api->CommInitRank(&comm, nranks, uid, rank));
+    const size_t row = (size_t)(3 + p->HM) * p->P;
+    const hipError_t e = hipMalloc(&p->d_gathered, row * nranks * 8);
+    if (e != hipSuccess) {
+        (void)api->CommDestroy(comm);
+        return fail(-2, std::string("hipMalloc of the gathered rows: ") + hipGetErrorString(e));
+    }
+    HIP_OK(hipMemset(p->d_gathered, 0, row * nranks * 8));
+    p->d_part_alloc = p->d_part;
+    p->d_part = p->d_gathered + row * rank;       // the statistics kernel writes where the gather expects them
+    p->comm = comm; p->comm_rank = rank; p->comm_nranks = nranks;
+    p->cfg_gen++;                   // captured updates were the single-rank kind
     return 0;
 }
 

@@ -234,6 +234,19 @@ class DevicePlanner:
     def merge(self, gathered_ptr, nranks, stream=None):
         L.check(L.lib().mppi_merge(self._h, L._vp(gathered_ptr), int(nranks), stream))
 
+    @staticmethod
+    def comm_unique_id():
+        """128-byte id of a new exchange group (made on one rank, handed to the others by the caller)."""
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().mppi_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        """Join the exchange group (collective over the ranks): iterate() and plan() then run sharded, with the
+        all-gather of the shard statistics made by the library on the planner's stream."""
+        assert len(unique_id) == 128
+        L.check(L.lib().mppi_comm_init(self._h, C.c_char_p(bytes(unique_id)), 128, int(rank), int(nranks)))
+
     def shift(self, override=None, stream=None):
         o = None if override is None else L.f64(override)
         L.check(L.lib().mppi_shift(self._h, L.ptr(o), stream))

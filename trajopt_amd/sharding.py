@@ -31,3 +31,37 @@ def all_gather_partials(part, world, out=None):
     else:
         dist.all_gather_into_tensor(out, part)
     return out
+
+
+def merge_rows(gathered, base, kappa):
+    """The merge every rank applies to the gathered statistics rows, on the host (numpy): the arithmetic of the
+    device's merge kernel, in rank order.  gathered: (world, 3 + H*M) rows [Rmax, global arg-max, sum S,
+    sum S*eps]; base: (H, M) act_sequence the samples were drawn around.  Returns (act_sequence, Rmax, arg-max);
+    ties for the maximum go to the lowest rank, whose arg-max is already its first one (`np.argmax` order)."""
+    import numpy as np
+    g = np.asarray(gathered, dtype=np.float64)
+    base = np.asarray(base, dtype=np.float64)
+    gmax, gidx = -np.inf, 0
+    for row in g:
+        if row[0] > gmax:
+            gmax, gidx = row[0], int(row[1])
+    den = 0.0
+    num = np.zeros(base.size)
+    for row in g:
+        w = np.exp(kappa * (row[0] - gmax))
+        den += w * row[2]
+        num += w * row[3:]
+    seq = (base.ravel() * den + num) / (den + 1e-6)
+    return seq.reshape(base.shape), gmax, gidx
+
+
+def init_library_exchange(planner, rank, world, device=None):
+    """Set up the in-library exchange of a sharded DevicePlanner: rank 0 makes the 128-byte group id, the
+    process group (any backend) broadcasts it, every rank joins.  With world == 1 no process group is needed."""
+    uid = planner.comm_unique_id() if rank == 0 else bytes(128)
+    if world > 1:
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=(device if on_gpu else "cpu"))
+        dist.broadcast(t, src=0)
+        uid = bytes(t.cpu().tolist())
+    planner.comm_init(uid, rank, world)

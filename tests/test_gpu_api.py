@@ -1,5 +1,6 @@
 """The reference's Python API on the HIP path: env duck-type, rollout helpers, MPPI.train_step.
 Needs a GPU (`-m gpu`).  The oracle is only the checker."""
+import os
 import pickle
 
 import numpy as np
@@ -165,27 +166,74 @@ def test_update_with_paths_and_critic():
         assert len(ag.sol_state) == before + 1
 
 
-def test_dense_planning_reaches_the_target():
-    """Behavioural acceptance with the hyper-parameters of the reference's example script
-    (sandbox/examples/reacher_7dof_mppi.py:11-44, dense reward): the stored reference agent
-    collects -274.76 over 100 steps and ends 0.018 m from the target.  With 40 samples per step the closed loop
-    amplifies rounding differences, so one run's total moves between about -265 and -365 with the noise seed
-    (`tools/planning_spread.py`); the test takes four seeds."""
+def _example_agent(seed, dtype):
+    """The agent of the reference's example script (sandbox/examples/reacher_7dof_mppi.py:11-44, dense reward)."""
     from trajopt.algos.mppi import MPPI
     from trajopt.envs.utils import get_environment
+    e = get_environment('reacher_7dof')
+    e.reset_model(seed=3, goal=(0, 0, 0), alpha=1.0)
+    return MPPI(e, H=16, paths_per_cpu=40, num_cpu=1, kappa=25.0, gamma=1.0, mean=np.zeros(7), filter_coefs=FILTER,
+                default_act='mean', seed=seed, dtype=dtype)
+
+
+@pytest.fixture(scope="module")
+def closed_loop():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "closed_loop_oracle.npz"))
+    return {k: d[k] for k in d.files}
+
+
+def test_fp64_planning_against_the_oracle_loop_for_100_steps(closed_loop, oracle_sim):
+    """Acceptance, exact form: the example script's loop (H=16, K=40, niter=5, 100 steps) in fp64 against the same
+    loop on the CPU oracle (tests/golden/make_closed_loop_oracle.py).  The closed loop is chaotic -- five updates
+    per step with weights exp(25 dR) on 40 samples multiply a rounding difference by 10 to 100 per step, so two
+    fp64 implementations with different operation order agree to 1e-9 for about ten steps and are different
+    trajectories after twenty.  Hence two checks: the free-running trajectory for the steps it can be compared, and
+    EVERY one of the 100 steps with the oracle restarted from the device run's own state and act_sequence."""
+    g = closed_loop
+    goal = np.zeros(3)
+    for i, seed in enumerate(g["seeds"][:2]):
+        ag = _example_agent(int(seed), "f64")
+        worst_q = worst_seq = 0.0
+        for t in range(100):
+            s0, seq = ag.sol_state[-1], ag.act_sequence.copy()
+            ag.train_step(niter=5, goal=(0, 0, 0))
+            eps = ref_mppi.filter_noise(ref_mppi.all_raw_normals(int(seed) + t, 40, 1, 16, 7), FILTER)
+            for _ in range(5):
+                R = oracle_sim.rollout(s0["qp"], s0["qv"], goal, t, seq + eps, gamma=1.0)
+                seq = ref_mppi.update(seq + eps, R, 25.0)
+            q, v, _, r, _ = oracle_sim.env_step(s0["qp"], s0["qv"], goal, seq[0], t)
+            worst_q = max(worst_q, np.abs(ag.sol_state[-1]["qp"] - q).max(), np.abs(ag.sol_state[-1]["qv"] - v).max(),
+                          abs(ag.sol_reward[-1] - r))
+            worst_seq = max(worst_seq, np.abs(ag.act_sequence - ref_mppi.shift(seq, "mean", np.zeros(7))).max())
+        assert worst_q < 1e-8 and worst_seq < 1e-6, (int(seed), worst_q, worst_seq)
+        qp = np.array([s["qp"] for s in ag.sol_state[1:]])
+        err = np.abs(qp - g["qpos"][i]).max(axis=1)
+        assert err[:8].max() < 1e-8, (int(seed), err[:12])
+        # free running it stays a run of the same planner: inside the oracle's seed-to-seed spread
+        assert g["spread_totals"].min() - g["spread_totals"].std() < np.sum(ag.sol_reward) < g["spread_totals"].max() + g["spread_totals"].std()
+
+
+def test_fp32_planning_stays_inside_the_oracle_seed_spread(closed_loop):
+    """Acceptance, statistical form.  With 40 samples per step the closed loop is chaotic in the noise seed: the fp64
+    ORACLE loop itself collects between -354 and -264 over 16 seeds (mean -293, std 25; the reference's stored
+    agent: -274.76, 0.018 m from the target at the end).  An fp32 run decorrelates from the fp64 one after a few
+    dozen steps, so it is held to that distribution, not to a trajectory: every total within one standard
+    deviation of the oracle's range, the four-seed mean within one standard deviation of the oracle's mean."""
+    g = closed_loop
+    lo, hi = g["spread_totals"].min(), g["spread_totals"].max()
+    mean, std = g["spread_totals"].mean(), g["spread_totals"].std()
     totals = []
-    for seed in (3, 4, 5, 6):
-        e = get_environment('reacher_7dof')
-        e.reset_model(seed=3, goal=(0, 0, 0), alpha=1.0)
-        ag = MPPI(e, H=16, paths_per_cpu=40, num_cpu=1, kappa=25.0, gamma=1.0, mean=np.zeros(7), filter_coefs=FILTER,
-                  default_act='mean', seed=seed)
+    for seed in g["seeds"]:
+        ag = _example_agent(int(seed), "f32")
         for _ in range(100):
             ag.train_step(niter=5, goal=(0, 0, 0))
         totals.append(float(np.sum(ag.sol_reward)))
-        final = float(ag.sol_obs[-1][-1])
-        assert final < 0.06, (seed, final)
-        assert totals[-1] > -420.0, (seed, totals)
-    assert np.mean(totals) > -360.0, totals
+        assert float(ag.sol_obs[-1][-1]) < g["spread_final_dist"].max() + 0.02, (int(seed), float(ag.sol_obs[-1][-1]))
+        assert lo - std < totals[-1] < hi + std, (int(seed), totals, (lo, hi, std))
+    assert abs(np.mean(totals) - mean) < std, (totals, mean, std)
+    # the first steps are still the oracle's trajectory (fp32 tolerance)
+    qp = np.array([s["qp"] for s in ag.sol_state[1:6]])
+    assert np.abs(qp - g["qpos"][-1][:5]).max() < 1e-3
 
 
 def test_continual_env_resets_target_every_50_real_steps():

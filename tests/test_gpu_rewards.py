@@ -1,0 +1,173 @@
+"""The sparse, tracking and cooling rewards of `Reacher7DOFEnv._step` (trajopt/envs/reacher_env.py:53-79) in
+K x H rollouts, in the captured iteration / planning-step graphs, and at the end of the reference trajectory,
+against the CPU oracle.  Needs a GPU.
+
+Tolerances: fp64 kernels 1e-10 absolute; fp32 kernels relative 1e-4 on returns for the continuous rewards.  The
+sparse reward is a step function of the hand-target distance (100 / -10 / -100): an fp32 rollout may put a step
+whose distance lies within rounding of a threshold on the other side, so fp32 sparse rewards are compared step by
+step with the number of such steps bounded and every one of them checked to sit on a threshold.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_mppi
+
+pytestmark = pytest.mark.gpu
+FILTER = [np.ones(7), 0.25, 0.8, 0.0]
+K, H, T0 = 256, 32, 3
+
+
+@pytest.fixture(scope="module")
+def dm():
+    from trajopt_amd.device import DeviceModel
+    return DeviceModel.get("reacher_7dof")
+
+
+def _planner(dm, dtype, K=K, H=H, **kw):
+    from trajopt_amd.device import DevicePlanner
+    return DevicePlanner(dm, K, H, dtype=dtype, kappa=25.0, gamma=0.98, sigma=FILTER[0], betas=FILTER[1:],
+                         default_act="mean", **kw)
+
+
+def _scene(oracle_sim):
+    """Start pose with the hand 3 cm from the target (so that all three sparse levels occur once the arm is
+    shaken) and a reference path that wanders away from the hand."""
+    q0 = np.array([0.2, 0.4, -0.3, -0.9, 0.2, -0.4, 0.1])
+    hand = oracle_sim.fk_hand(q0)
+    target = hand + np.array([0.02, -0.015, 0.015])
+    rs = np.random.RandomState(12)
+    ref = hand + np.cumsum(rs.randn(T0 + H + 8, 3) * 0.01, axis=0)
+    return q0, np.zeros(7), target, ref
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("reward_type,alpha", [("sparse", 1.0), ("tracking", 1.0), ("cooling", 0.3)])
+def test_reward_types_in_rollouts(dm, oracle_sim, dtype, reward_type, alpha):
+    q0, v0, target, ref = _scene(oracle_sim)
+    raw = ref_mppi.raw_normals(21, K, H, 7)
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)
+    base = np.full((H, 7), 0.05)
+    p = _planner(dm, dtype, dump=True)
+    p.set_params(25.0, 0.98, reward_type)
+    p.set_start_state(q0, v0, target, T0)
+    p.set_reference(ref if reward_type != "sparse" else None, alpha)
+    p.set_base_actions(base)
+    p.upload_noise(raw)
+    p.rollout()
+    R, rew, nobs = p.returns(), p.rewards(), p.next_observations()
+    act = base + (eps if dtype == "f64" else eps.astype(np.float32).astype(np.float64))
+    R_o, nobs_o, rew_o = oracle_sim.rollout(q0, v0, target, T0, act, reward_type=reward_type,
+                                            reference=None if reward_type == "sparse" else ref, alpha=alpha,
+                                            gamma=0.98, dump=True)
+    assert p.status() == 0
+    if reward_type in ("sparse", "cooling"):
+        levels = set(np.unique(rew_o)) if reward_type == "sparse" else None
+        if levels is not None:
+            assert levels == {100.0, -10.0}, levels             # the scene exercises the near threshold
+    if dtype == "f64":
+        assert np.abs(rew - rew_o).max() < 1e-10 and np.abs(R - R_o).max() < 1e-9
+        assert np.abs(nobs - nobs_o).max() < 1e-10
+        assert int(np.argmax(R)) == int(np.argmax(R_o))
+    elif reward_type == "tracking":
+        assert np.abs(R - R_o).max() / np.abs(R_o).max() < 1e-4
+        assert np.abs(rew - rew_o).max() < 2e-3
+    else:
+        # steps whose sparse level differs must sit on a threshold of the distance
+        dist_o = np.linalg.norm(nobs_o[..., 14:17] - nobs_o[..., 17:20], axis=-1)
+        sparse_gap = 110.0 * (1.0 - alpha if reward_type == "cooling" else 1.0)
+        flipped = np.abs(rew - rew_o) > 0.5 * sparse_gap
+        assert flipped.mean() < 2e-3, flipped.mean()
+        assert (np.minimum(np.abs(dist_o[flipped] - 0.025), np.abs(dist_o[flipped] - 0.8)) < 1e-5).all()
+        assert np.abs((rew - rew_o)[~flipped]).max() < 2e-3
+    p.close()
+
+
+def test_far_threshold_of_the_sparse_reward(dm, oracle_sim):
+    """hand-target distance beyond 0.8 scores -100 (reacher_env.py:56-57): the rest pose is 1.02 m from the origin."""
+    raw = ref_mppi.raw_normals(2, 64, 8, 7)
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)
+    p = _planner(dm, "f64", K=64, H=8, dump=True)
+    p.set_params(25.0, 1.0, "sparse")
+    p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), 0)
+    p.set_base_actions(np.zeros((8, 7)))
+    p.upload_noise(raw)
+    p.rollout()
+    assert (p.rewards() == -100.0).all()
+    assert np.array_equal(p.returns(), oracle_sim.rollout(np.zeros(7), np.zeros(7), np.zeros(3), 0, eps, reward_type="sparse"))
+    p.close()
+
+
+@pytest.mark.parametrize("reward_type,alpha", [("tracking", 1.0), ("cooling", 0.6)])
+def test_reference_rewards_inside_the_captured_graphs(dm, oracle_sim, reward_type, alpha):
+    """iterate() (graph of one iteration) and plan() (graph of a whole step) with a reference trajectory set:
+    the update against the oracle's returns, and plan() against the same step made of separate calls."""
+    q0, v0, target, ref = _scene(oracle_sim)
+    raw = ref_mppi.raw_normals(8, K, H, 7)
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)
+    base = np.zeros((H, 7))
+    p = _planner(dm, "f64")
+    p.set_params(25.0, 0.98, reward_type)
+    p.set_start_state(q0, v0, target, T0)
+    p.set_reference(ref, alpha)
+    p.set_base_actions(base)
+    p.upload_noise(raw)
+    p.iterate(1)
+    R_o = oracle_sim.rollout(q0, v0, target, T0, base + eps, reward_type=reward_type, reference=ref, alpha=alpha, gamma=0.98)
+    assert np.abs(p.returns() - R_o).max() < 1e-9
+    assert np.abs(p.act_sequence() - ref_mppi.update(base + eps, R_o, 25.0)).max() < 1e-9
+    # alpha changes between iterations without a re-capture (it lives in the device state): same graph, new values
+    p.set_base_actions(base)
+    p.set_reference(ref, 0.5 * alpha)
+    p.iterate(1)
+    R_o2 = oracle_sim.rollout(q0, v0, target, T0, base + eps, reward_type=reward_type, reference=ref, alpha=0.5 * alpha, gamma=0.98)
+    assert np.abs(p.returns() - R_o2).max() < 1e-9
+    p.close()
+    # whole planning steps: graph replays against separate calls, real-env rewards included
+    a, b = _planner(dm, "f32"), _planner(dm, "f32")
+    for x in (a, b):
+        x.set_params(25.0, 0.98, reward_type)
+        x.set_start_state(q0, v0, target, T0)
+        x.set_reference(ref, alpha)
+        x.set_base_actions(base)
+    steps = 4
+    a.plan(5, niter=2, nsteps=steps)
+    for _ in range(steps):
+        b.generate_noise_step(5)
+        b.iterate(2)
+        b.advance()
+    la, lb = a.read_log(), b.read_log()
+    assert la["total"] == lb["total"] == steps
+    for key in ("qpos", "qvel", "reward", "action"):
+        assert np.array_equal(la[key], lb[key]), key
+    # the real-env reward of every logged step is the oracle's for that transition
+    q, v = q0, v0
+    for i in range(steps):
+        q, v, _, r, _ = oracle_sim.env_step(q, v, target, la["action"][i], env_timestep=T0 + i, reward_type=reward_type,
+                                            reference=ref, alpha=alpha)
+        assert abs(r - la["reward"][i]) < 1e-9 and np.abs(q - la["qpos"][i]).max() < 1e-10
+    a.close(); b.close()
+
+
+def test_end_of_the_reference_raises_like_the_reference(dm):
+    """`self.reference[self.env_timestep]` runs off the end once timestep + H >= len(reference): IndexError from
+    train_step, from the rollout helpers and from the single env step."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    from trajopt.utils import gather_paths_parallel
+    Hs = 6
+    ref = np.zeros((Hs + 3, 3)) + np.array([0.6, -0.4, 0.1])
+    e = get_environment('reacher_7dof', reward_type='tracking', reference=ref)
+    e.reset_model(goal=(0.0, 0.0, 0.0))
+    ag = MPPI(e, H=Hs, paths_per_cpu=16, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=1,
+              reward_type='tracking', reference=ref)
+    for _ in range(3):                       # timestep 0, 1, 2: the last index used is timestep + H <= 8
+        ag.train_step(niter=1)
+    with pytest.raises(IndexError):
+        ag.train_step(niter=1)               # timestep 3: index 9 of 9 rows
+    with pytest.raises(IndexError):
+        gather_paths_parallel('reacher_7dof', ag.sol_state[-1], ag.act_sequence, FILTER, 1, None, 'tracking', ref, 1.0, 8, 1)
+    with pytest.raises(TypeError):
+        gather_paths_parallel('reacher_7dof', ag.sol_state[0], ag.act_sequence, FILTER, 1, None, 'cooling', None, 1.0, 8, 1)
+    e.env_timestep = len(ref) - 1            # the real env: reference[env_timestep + 1]
+    with pytest.raises(IndexError):
+        e.step(np.zeros(7))

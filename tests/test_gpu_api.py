@@ -360,6 +360,46 @@ def test_device_critic_equals_host_critic(oracle_sim, dim):
     assert np.abs(p.returns() - (rew * 0.9 ** np.arange(H)).sum(1)).max() < 1e-3
 
 
+@pytest.mark.parametrize("dim", [6, 14, 17])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_device_critic_with_the_reference_trained_weights(oracle_sim, dim, dtype):
+    """The matrix-core critic kernel with weights the reference trained and stored (tests/golden/critic_vectors.npz,
+    whose values pin this package's torch `Critic` to the reference's): terminal values of K = 1000 rollouts (a
+    ragged last block) against torch on the oracle's final observations.  fp32 network, tolerance 1e-4 of the
+    value range (rollout fp32 error included for f32; 2e-5 for fp64 rollouts, where only the network differs)."""
+    import torch
+    from trajopt.models.critic_nets import Critic
+    from trajopt_amd.algos.mppi import _critic_weights
+    from trajopt_amd.device import DeviceModel, DevicePlanner
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "critic_vectors.npz"))
+    critic = Critic(input_dim=dim)
+    critic.load_state_dict({"linear1.weight": torch.tensor(g["w%d_W1" % dim]), "linear1.bias": torch.tensor(g["w%d_b1" % dim]),
+                            "linear2.weight": torch.tensor(g["w%d_W2" % dim]), "linear2.bias": torch.tensor(g["w%d_b2" % dim]),
+                            "linear3.weight": torch.tensor(g["w%d_W3" % dim]), "linear3.bias": torch.tensor(g["w%d_b3" % dim])})
+    K, H, gamma = 1000, 6, 0.95
+    goal = np.array([0.05, -0.05, 0.1])
+    q0 = np.array([0.2, 0.4, -0.3, -0.9, 0.2, -0.4, 0.1])
+    raw = ref_mppi.raw_normals(6, K, H, 7)
+    eps = ref_mppi.filter_noise(raw.copy(), FILTER)
+    p = DevicePlanner(DeviceModel.get("reacher_7dof"), K, H, kappa=5.0, gamma=gamma, sigma=FILTER[0], betas=FILTER[1:], dtype=dtype)
+    p.set_start_state(q0, np.zeros(7), goal, 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.upload_noise(raw)
+    p.set_critic(dim, _critic_weights(critic, dim))
+    p.rollout()
+    R = p.returns()
+    _, nobs, rew = oracle_sim.rollout(q0, np.zeros(7), goal, 0, eps, gamma=gamma, dump=True)
+    obs = torch.tensor(nobs[:, -1], dtype=torch.float32)
+    x = {14: obs[:, :14], 17: torch.cat((obs[:, :14], obs[:, -3:]), 1), 6: obs[:, -6:]}[dim]
+    with torch.no_grad():
+        V = critic(x).numpy().reshape(-1).astype(np.float64)
+    want = (rew[:, :-1] * gamma ** np.arange(H - 1)).sum(1) + gamma ** (H - 1) * V
+    scale = np.abs(V).max()
+    assert scale > 10.0                              # trained critics: values of the order of the returns
+    assert np.abs(R - want).max() < (1e-4 if dtype == "f32" else 2e-5) * scale, np.abs(R - want).max()
+    p.close()
+
+
 def test_example_script_flow():
     """examples/reacher_goals.py: random goals, 116 steps, pickle round trip, sparse replay."""
     import importlib.util, os

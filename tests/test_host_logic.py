@@ -103,3 +103,24 @@ def test_unknown_env_and_missing_kernel():
     ag = MPPI(ToyEnv(), H=3, paths_per_cpu=4)
     with pytest.raises(ValueError):
         ag.train_step()          # no compiled rollout kernel for the toy env: fails loudly, no CPU fallback
+
+
+def test_critic_module_reproduces_the_reference_module_on_its_trained_weights():
+    """`Critic` loaded with three of the reference's stored state_dicts (input widths 6, 14, 17) gives the values the
+    reference's own module gave on the same observations (tests/golden/make_critic_vectors.py)."""
+    import os
+    import torch
+    from trajopt_amd.models.critic_nets import Critic
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "critic_vectors.npz"))
+    obs = torch.tensor(g["obs"], dtype=torch.float32)
+    for dim in (6, 14, 17):
+        c = Critic(input_dim=dim)
+        c.load_state_dict({"linear1.weight": torch.tensor(g["w%d_W1" % dim]), "linear1.bias": torch.tensor(g["w%d_b1" % dim]),
+                           "linear2.weight": torch.tensor(g["w%d_W2" % dim]), "linear2.bias": torch.tensor(g["w%d_b2" % dim]),
+                           "linear3.weight": torch.tensor(g["w%d_W3" % dim]), "linear3.bias": torch.tensor(g["w%d_b3" % dim])})
+        x = {6: obs[:, -6:], 14: obs[:, :14], 17: torch.cat((obs[:, :14], obs[:, -3:]), 1)}[dim]
+        with torch.no_grad():
+            v = c(x).numpy().reshape(-1)
+        assert np.abs(v - g["v%d" % dim]).max() < 1e-4 * np.abs(g["v%d" % dim]).max()
+        # the slicing helper the example scripts use gives the same inputs
+        assert np.array_equal(np.stack([c.compress_state(o, dim) for o in g["obs"]]).astype(np.float32), x.numpy())

@@ -373,57 +373,143 @@ __global__ void __launch_bounds__(256) advance_noise_kernel(DevState* __restrict
 // ------------------------------------------------------------------------------------------
 // terminal-value critic: tanh MLP in -> 128 -> 128 -> 1 on the final observation of every sample
 // (trajopt/models/critic_nets.py:47-60; input slices trajopt/algos/mppi.py:138-154), fp32 like the
-// reference's torch module.  One lane per sample; weights are wave-uniform (scalar loads).
-// R[k] += gamma^(H-1) * V(x_k): the rollout left the last reward out (trajopt/algos/mppi.py:97-101).
+// reference's torch module.  R[k] += gamma^(H-1) * V(x_k): the rollout left the last reward out
+// (trajopt/algos/mppi.py:97-101).
+//
+// The two hidden layers are matrix products and run on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands,
+// fp32 accumulation).  A block of four waves serves 32 samples.  Everything is computed transposed,
+// hidden[unit][sample] = W[unit][k] x[k][sample], so that a layer's output tile -- 16 registers per lane: column =
+// sample lane % 32, rows = units 8 (v / 4) + 4 (lane / 32) + v % 4 -- is, register by register, already the
+// B operand (k = that unit, column = sample) of the next layer's products: no value changes lane between the
+// layers.  The weights are stored in the order the A operand wants them (pack_critic_weights), one contiguous
+// 256-byte read per product.  Every wave computes all of layer 1 (36 products) and one 32-unit tile of layer 2
+// (64 products); the last layer's dot product is reduced over the block in a fixed order.
 // ------------------------------------------------------------------------------------------
 constexpr int CRITIC_INNER = 128;
 constexpr int CRITIC_IN = 17;          // widest input (qpos, qvel, goal); narrower inputs are zero padded
+constexpr int CRITIC_K1 = 18;          // layer-1 contraction length: CRITIC_IN padded to a whole number of k-pairs
+constexpr int CRITIC_TILES = CRITIC_INNER / 32;
+// packed block: [W1p (4 tiles x 9 k-pairs x 64 lanes) | b1 (128) | W2p (4 x 4 tiles x 16 registers x 64 lanes) | b2 (128) | W3 (128) | b3]
+constexpr size_t CRITIC_W1P = CRITIC_TILES * (CRITIC_K1 / 2) * 64;
+constexpr size_t CRITIC_W2P = (size_t)CRITIC_TILES * CRITIC_TILES * 16 * 64;
+constexpr size_t CRITIC_W_FLOATS = CRITIC_W1P + CRITIC_INNER + CRITIC_W2P + CRITIC_INNER + CRITIC_INNER + 1;
+
+// unit (row of the 32-row output tile) that register v of a lane in half-wave `half` holds
+MPPI_HD int critic_tile_row(int v, int half) { return 8 * (v / 4) + 4 * half + (v % 4); }
+
+// torch's row-major weights (W1 [128][dim], W2 [128][128], W3 [128]) -> the packed block
+inline void pack_critic_weights(int dim, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                float b3, float* out) {
+    float* o = out;
+    for (int t = 0; t < CRITIC_TILES; t++)
+        for (int kk = 0; kk < CRITIC_K1 / 2; kk++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int unit = 32 * t + lane % 32, k = 2 * kk + lane / 32;
+                *o++ = k < dim ? W1[unit * dim + k] : 0.f;
+            }
+    for (int j = 0; j < CRITIC_INNER; j++) *o++ = b1[j];
+    for (int t2 = 0; t2 < CRITIC_TILES; t2++)
+        for (int t = 0; t < CRITIC_TILES; t++)
+            for (int v = 0; v < 16; v++)
+                for (int lane = 0; lane < 64; lane++)
+                    *o++ = W2[(32 * t2 + lane % 32) * CRITIC_INNER + 32 * t + critic_tile_row(v, lane / 32)];
+    for (int j = 0; j < CRITIC_INNER; j++) *o++ = b2[j];
+    for (int j = 0; j < CRITIC_INNER; j++) *o++ = W3[j];
+    *o++ = b3;
+}
+
+typedef float critic_acc_t __attribute__((ext_vector_type(16)));
+
+// tanh(x) = 1 - 2 / (1 + e^(2x)) on the hardware exponential and reciprocal: absolute error about 2e-7 (one fp32
+// rounding of a value near 1), a sixth of the instructions of the library routine; saturates correctly for large |x|
+__device__ __forceinline__ float critic_tanh(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // e^(2x) = 2^(2x log2 e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+#else
+    return tanhf(x);
+#endif
+}
 
 template <class T, int NV>
-__global__ void __launch_bounds__(64) critic_kernel(const T* __restrict__ fobs, int K, int dim, const float* __restrict__ W1,
-                                                    const float* __restrict__ b1, const float* __restrict__ W2,
-                                                    const float* __restrict__ b2, const float* __restrict__ W3,
-                                                    double g_last, T* __restrict__ R) {
+__global__ void __launch_bounds__(256) critic_kernel(const T* __restrict__ fobs, int K, int dim, const float* __restrict__ w,
+                                                     double g_last, T* __restrict__ R) {
+#if defined(__HIP_DEVICE_COMPILE__)
     constexpr int OD = 2 * NV + 6;
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ float s_part[CRITIC_TILES][32];
+    const float* __restrict__ W1p = w;
+    const float* __restrict__ b1 = W1p + CRITIC_W1P;
+    const float* __restrict__ W2p = b1 + CRITIC_INNER;
+    const float* __restrict__ b2 = W2p + CRITIC_W2P;
+    const float* __restrict__ W3 = b2 + CRITIC_INNER;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+    const int k = blockIdx.x * 32 + col;                  // this lane's sample (lanes col and col + 32 share it)
     fobs += (size_t)blockIdx.y * K * OD;
     R += (size_t)blockIdx.y * K;
-    const T* o = fobs + (size_t)k * OD;
-    float x[CRITIC_IN];
+    float x[CRITIC_K1];
 #pragma unroll
-    for (int i = 0; i < CRITIC_IN; i++) x[i] = 0.f;
-    if (dim == 14 || dim == 15 || dim == 17) {
+    for (int i = 0; i < CRITIC_K1; i++) x[i] = 0.f;
+    if (k < K) {
+        const T* o = fobs + (size_t)k * OD;
+        if (dim == 14 || dim == 15 || dim == 17) {
 #pragma unroll
-        for (int i = 0; i < 14; i++) x[i] = (float)o[i];
-        if (dim == 15) {
-            const float dx = (float)o[OD - 6] - (float)o[OD - 3], dy = (float)o[OD - 5] - (float)o[OD - 2], dz = (float)o[OD - 4] - (float)o[OD - 1];
-            x[14] = sqrtf(dx * dx + dy * dy + dz * dz);
-        } else if (dim == 17) {
-            x[14] = (float)o[OD - 3]; x[15] = (float)o[OD - 2]; x[16] = (float)o[OD - 1];
+            for (int i = 0; i < 14; i++) x[i] = (float)o[i];
+            if (dim == 15) {
+                const float dx = (float)o[OD - 6] - (float)o[OD - 3], dy = (float)o[OD - 5] - (float)o[OD - 2], dz = (float)o[OD - 4] - (float)o[OD - 1];
+                x[14] = sqrtf(dx * dx + dy * dy + dz * dz);
+            } else if (dim == 17) {
+                x[14] = (float)o[OD - 3]; x[15] = (float)o[OD - 2]; x[16] = (float)o[OD - 1];
+            }
+        } else if (dim == 3) {
+            x[0] = (float)o[OD - 6]; x[1] = (float)o[OD - 5]; x[2] = (float)o[OD - 4];
+        } else {  // 6
+#pragma unroll
+            for (int i = 0; i < 6; i++) x[i] = (float)o[OD - 6 + i];
         }
-    } else if (dim == 3) {
-        x[0] = (float)o[OD - 6]; x[1] = (float)o[OD - 5]; x[2] = (float)o[OD - 4];
-    } else {  // 6
-#pragma unroll
-        for (int i = 0; i < 6; i++) x[i] = (float)o[OD - 6 + i];
     }
-    float h1[CRITIC_INNER];
+    // layer 1, all four tiles: B operand of k-pair kk is x[2 kk + half] of the lane's sample
+    critic_acc_t h1[CRITIC_TILES];
 #pragma unroll
-    for (int j = 0; j < CRITIC_INNER; j++) {
-        float a = b1[j];
+    for (int t = 0; t < CRITIC_TILES; t++) {
+        critic_acc_t acc;
 #pragma unroll
-        for (int i = 0; i < CRITIC_IN; i++) a = fmaf(W1[j * CRITIC_IN + i], x[i], a);
-        h1[j] = tanhf(a);
+        for (int v = 0; v < 16; v++) acc[v] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < CRITIC_K1 / 2; kk++) {
+            const float a = W1p[(size_t)(t * (CRITIC_K1 / 2) + kk) * 64 + lane];
+            const float b = half ? x[2 * kk + 1] : x[2 * kk];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; v++) h1[t][v] = critic_tanh(acc[v] + b1[32 * t + critic_tile_row(v, half)]);
     }
-    float out = W3[CRITIC_INNER];          // b3 follows W3 in the packed weight block
-    for (int j = 0; j < CRITIC_INNER; j++) {
-        float a = b2[j];
+    // layer 2, tile `wave`: register v of layer-1 tile t is the B operand whose k is the unit that register holds
+    critic_acc_t acc;
 #pragma unroll
-        for (int i = 0; i < CRITIC_INNER; i++) a = fmaf(W2[j * CRITIC_INNER + i], h1[i], a);
-        out = fmaf(W3[j], tanhf(a), out);
+    for (int v = 0; v < 16; v++) acc[v] = 0.f;
+#pragma unroll
+    for (int t = 0; t < CRITIC_TILES; t++) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const float a = W2p[((size_t)(wave * CRITIC_TILES + t) * 16 + v) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[t][v], acc, 0, 0, 0);
+        }
     }
-    R[k] = R[k] + T(g_last) * T(out);
+    // layer 3: this wave's 32 units, 16 of them in each half-wave
+    float part = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int unit = 32 * wave + critic_tile_row(v, half);
+        part = fmaf(W3[unit], critic_tanh(acc[v] + b2[unit]), part);
+    }
+    part += __shfl_xor(part, 32, 64);
+    if (half == 0) s_part[wave][col] = part;
+    __syncthreads();
+    if (wave == 0 && half == 0 && k < K) {
+        const float out = W3[CRITIC_INNER] + (((s_part[0][col] + s_part[1][col]) + s_part[2][col]) + s_part[3][col]);
+        R[k] = R[k] + T(g_last) * T(out);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -684,20 +770,13 @@ static hipError_t launch_env_step(const double* in, int reward_type, int has_ref
     hipLaunchKernelGGL((env_step_kernel<MD>), dim3(1), dim3(64), 0, s, in, reward_type, has_ref, forward_only, out);
     return hipGetLastError();
 }
-// w: [W1 (128 x 17, zero padded) | b1 (128) | W2 (128 x 128) | b2 (128) | W3 (128) | b3 (1)]
-constexpr size_t CRITIC_W_FLOATS = CRITIC_INNER * CRITIC_IN + CRITIC_INNER + CRITIC_INNER * CRITIC_INNER + CRITIC_INNER + CRITIC_INNER + 1;
 template <class MD>
 static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t s) {
-    const float* W1 = w;
-    const float* b1 = W1 + CRITIC_INNER * CRITIC_IN;
-    const float* W2 = b1 + CRITIC_INNER;
-    const float* b2 = W2 + CRITIC_INNER * CRITIC_INNER;
-    const float* W3 = b2 + CRITIC_INNER;
-    const dim3 grid((K + 63) / 64, P), block(64);
+    const dim3 grid((K + 31) / 32, P), block(256);
     if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((critic_kernel<float, MD::NV>), grid, block, 0, s, (const float*)fobs, K, dim, W1, b1, W2, b2, W3, g_last, (float*)R);
+        hipLaunchKernelGGL((critic_kernel<float, MD::NV>), grid, block, 0, s, (const float*)fobs, K, dim, w, g_last, (float*)R);
     else
-        hipLaunchKernelGGL((critic_kernel<double, MD::NV>), grid, block, 0, s, (const double*)fobs, K, dim, W1, b1, W2, b2, W3, g_last, (double*)R);
+        hipLaunchKernelGGL((critic_kernel<double, MD::NV>), grid, block, 0, s, (const double*)fobs, K, dim, w, g_last, (double*)R);
     return hipGetLastError();
 }
 template <class MD>

@@ -516,15 +516,7 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
     if (inner != CRITIC_INNER) return fail(-1, "only the 128-wide critic has a compiled kernel");
     if (!W1 || !b1 || !W2 || !b2 || !W3) return fail(-1, "null critic weights");
     std::vector<float> w(CRITIC_W_FLOATS, 0.f);
-    float* o = w.data();
-    for (int j = 0; j < CRITIC_INNER; j++)
-        for (int i = 0; i < dim; i++) o[j * CRITIC_IN + i] = W1[j * dim + i];
-    o += CRITIC_INNER * CRITIC_IN;
-    std::memcpy(o, b1, CRITIC_INNER * 4); o += CRITIC_INNER;
-    std::memcpy(o, W2, CRITIC_INNER * CRITIC_INNER * 4); o += CRITIC_INNER * CRITIC_INNER;
-    std::memcpy(o, b2, CRITIC_INNER * 4); o += CRITIC_INNER;
-    std::memcpy(o, W3, CRITIC_INNER * 4); o += CRITIC_INNER;
-    *o = b3;
+    pack_critic_weights(dim, W1, b1, W2, b2, W3, b3, w.data());
     if (!p->d_critic) HIP_OK(hipMalloc(&p->d_critic, CRITIC_W_FLOATS * 4));
     if (!p->d_fobs) HIP_OK(hipMalloc(&p->d_fobs, (size_t)p->cfg.K * p->P * (p->nq + p->nv + 6) * p->esz));
     HIP_OK(hipMemcpy(p->d_critic, w.data(), CRITIC_W_FLOATS * 4, hipMemcpyHostToDevice));

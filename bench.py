@@ -92,7 +92,7 @@ def flops_per_env_step():
 def measured_traffic():
     """HBM bytes per rollout launch from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE
     passes, gfx950 corrections applied); None if the summary is not for this workload."""
-    path = os.path.join(ROOT, "profiles", "r1g_rollout_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_rollout_traffic.json")
     try:
         d = json.load(open(path))
         if d.get("K") == K_PER_GPU and d.get("H") == H:

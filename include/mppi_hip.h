@@ -243,6 +243,12 @@ int mppi_update_from_returns(int32_t device, const double* act_KxHM, const doubl
 int mppi_update_from_returns_noalloc(int32_t device, const double* d_act_KxHM, const double* d_R, int32_t K, int32_t HM,
                                      double kappa, double* d_act_seq_out, void* stream);
 
+/* Host utility: the first n values of numpy's legacy normal stream after `np.random.seed(seed)` -- what the
+ * reference's rollout workers draw (trajopt/utils.py:118-139) -- bit for bit, generated in bulk on nthreads host
+ * threads (several times faster than numpy's one-value-at-a-time generator).  state_out, if not NULL, receives 628
+ * words: what np.random.get_state() would hold afterwards (key[624], pos, has_gauss, cached variate as two words). */
+int mppi_numpy_normals(uint32_t seed, size_t n, double* out, int32_t nthreads, uint32_t* state_out);
+
 /* Philox-4x32-10 block function (host), for known-answer tests of the device generator. */
 void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -26,8 +26,11 @@ python3 "$R/tools/summarize_pmc.py" sq "$O/pmc_sq" > "$O/rollout_pmc_sq.json"
 python3 "$R/tools/summarize_pmc.py" hbm "$O/pmc_fetch" "$O/pmc_write" > "$O/rollout_traffic.json"
 echo "counters done"
 
-timeout -k 10 120 python3 "$R/tools/ksweep.py" 4096 65536 262144 524288 > "$O/ksweep.jsonl" 2> /dev/null
+MPPI_BENCH_SHARDED=1 timeout -k 10 300 python3 "$R/bench.py" --no-cpu-baseline > "$O/bench_sharded_one_rank.json" 2> /dev/null
+timeout -k 10 120 python3 "$R/tools/ksweep.py" 4096 8192 16384 32768 65536 131072 262144 524288 > "$O/ksweep.jsonl" 2> /dev/null
 timeout -k 10 120 python3 "$R/tools/step_breakdown.py" 4096 > "$O/step_breakdown.txt" 2> /dev/null
+timeout -k 10 120 python3 "$R/tools/step_breakdown.py" 8192 >> "$O/step_breakdown.txt" 2> /dev/null
+timeout -k 10 120 python3 "$R/tools/step_breakdown.py" 65536 >> "$O/step_breakdown.txt" 2> /dev/null
 timeout -k 10 120 python3 "$R/tools/step_breakdown.py" 512 1024 >> "$O/step_breakdown.txt" 2> /dev/null
 timeout -k 10 180 python3 "$R/tools/bench_planners.py" > "$O/planners.jsonl" 2> /dev/null
 timeout -k 10 180 python3 "$R/tools/time_train_step.py" > "$O/train_step.jsonl" 2> /dev/null

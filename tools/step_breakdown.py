@@ -13,6 +13,7 @@ lead = (P,) if P > 1 else ()
 p.set_start_state(np.zeros(lead + (7,)), np.zeros(lead + (7,)), np.zeros(lead + (3,)), 0)
 p.set_base_actions(np.zeros(lead + (64, 7)))
 s = torch.cuda.current_stream().cuda_stream
+print("K = %d, planners = %d" % (K, P))
 def timeit(name, fn, n=300 if P == 1 else 30):
     for _ in range(20): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -86,6 +86,7 @@ _PROTOS = {
     "mppi_env_forward": (C.c_int, [_vp, _i32, _vp, _vp]),
     "mppi_update_from_returns": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _d, _vp]),
     "mppi_update_from_returns_noalloc": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _d, _vp, _vp]),
+    "mppi_numpy_normals": (C.c_int, [C.c_uint32, C.c_size_t, _vp, _i32, _vp]),
     "mppi_philox4x32": (None, [_vp, _vp, _vp]),
 }
 EXPORTS = tuple(_PROTOS)

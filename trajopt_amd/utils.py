@@ -205,18 +205,38 @@ def do_env_rollout(env_name, start_state, act_list, goal, reward_type, reference
     return _paths_from_device(p, start_state, p.actions(), env_name)
 
 
+_HOST_THREADS = None
+
+
+def _host_threads():
+    global _HOST_THREADS
+    if _HOST_THREADS is None:
+        import os
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        _HOST_THREADS = max(1, min(16, n, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    return _HOST_THREADS
+
+
 def worker_normals(base_seed, n_paths, H, m, in_process=True):
     """Raw N(0,1) draws of one reference worker: seed once, then n_paths blocks of (H, m) in
-    order (`generate_paths`, trajopt/utils.py:135-139).  in_process: the worker is the calling process itself
-    (the reference's num_cpu == 1 path, trajopt/utils.py:171-172), so the process-global numpy stream is
-    re-seeded and left advanced as there; pool workers re-seed only their own copy of it, which a private
-    generator with the same legacy stream stands for."""
+    order (`generate_paths`, trajopt/utils.py:135-139) -- numpy's legacy stream, produced in bulk by the
+    library's generator (same bits as `np.random.seed(base_seed)` + `np.random.normal(size=(H, m))` calls).
+    in_process: the worker is the calling process itself (the reference's num_cpu == 1 path,
+    trajopt/utils.py:171-172), which leaves the process-global numpy generator re-seeded and advanced past the
+    draws: the global state is set to exactly that.  Pool workers re-seed only their own copy, so with several
+    workers the caller's generator is left alone."""
+    from . import _lib as L
+    seed = int(base_seed)
+    if not 0 <= seed < 2 ** 32:
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    out = np.empty((n_paths, H, m))
+    state = np.empty(628, dtype=np.uint32) if in_process else None
+    rc = L.lib().mppi_numpy_normals(seed, out.size, L.ptr(out), _host_threads(), L.ptr(state))
+    if rc != 0:
+        raise RuntimeError("mppi_numpy_normals failed")
     if in_process:
-        np.random.seed(base_seed)
-        draw = np.random.normal
-    else:
-        draw = np.random.RandomState(base_seed).normal
-    return np.stack([draw(loc=0, scale=1.0, size=(H, m)) for _ in range(n_paths)])
+        np.random.set_state(("MT19937", state[:624], int(state[624]), int(state[625]), float(state[626:628].view(np.float64)[0])))
+    return out
 
 
 def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m):

@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 K_PER_GPU, H, M = 4096, 64, 7
 K_STRONG = 65536                   # the sharded planner of the multi-GPU runs
+K_STRONG_LARGE = 524288            # a second, larger sharded planner, reported beside it (N > 1 only)
 KAPPA, GAMMA = 25.0, 1.0
 FILTER = [np.ones(M), 0.25, 0.8, 0.0]
 SEED = 123
@@ -246,10 +247,54 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms, launches = p.profile_read()
     p.profile(False)
+    log = p.read_log(args.steps + args.warmup)
+    log_total = int(log["total"])
+    log_dist = float(np.linalg.norm(log["hand"][-1] - log["target"][-1]))
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # The same measurement for a planner eight times larger, where every GPU still has 65536 samples at N = 8:
+    # K = 65536 is one wavefront per SIMD of ONE GPU, so sharding it only empties SIMDs (a rollout takes as long as
+    # one sample's instruction stream however few samples a GPU holds); this second point shows the scaling of the
+    # same code once there is work to share.  Reported under "strong_scaling_large", outside the timed region above.
+    large = None
+    # (MPPI_BENCH_LARGE=1 with MPPI_BENCH_SHARDED=1 rehearses this block on one rank)
+    if (world > 1 or (sharded and os.environ.get("MPPI_BENCH_LARGE") == "1")) and not torch_exchange:
+        p.close()
+        t1_large = None
+        if rank == 0:
+            p1 = make_planner(K_STRONG_LARGE, 0, local_rank)
+            for _ in range(3):
+                p1.plan(SEED, 1, 1, sptr)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                p1.plan(SEED, 1, 1, sptr)
+            torch.cuda.synchronize()
+            t1_large = 1e3 * (time.perf_counter() - t0) / 20
+            p1.close()
+        barrier()
+        KL = K_STRONG_LARGE // world
+        pl = make_planner(KL, rank * KL, local_rank)
+        sharding.init_library_exchange(pl, rank, world, device="cuda:%d" % local_rank)
+        for _ in range(5):
+            pl.plan(SEED, 1, 1, sptr)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            pl.plan(SEED, 1, 1, sptr)
+        barrier()
+        tl = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        tn_large = 1e3 * float(tl.item()) / 40
+        pl.close()
+        if rank == 0:
+            large = {"K_total": K_STRONG_LARGE, "one_gpu_ms_per_step": t1_large, "n_gpu_ms_per_step": tn_large,
+                     "efficiency": t1_large / (world * tn_large),
+                     "env_steps_per_sec": K_STRONG_LARGE * H / (tn_large * 1e-3)}
 
     if rank == 0:
         env_steps = K_total * H * args.steps
@@ -284,11 +329,12 @@ def main():
             # T(1 GPU, K) / (N * T(N GPUs, K)), both measured in this run
             out["strong_scaling"] = {"K_total": K_total, "one_gpu_ms_per_step": t1_ms, "n_gpu_ms_per_step": ms_step,
                                      "efficiency": t1_ms / (world * ms_step)}
+        if large is not None:
+            out["strong_scaling_large"] = large
         if base is not None:
             out["cpu_baseline"] = base
-        log = p.read_log(args.steps + args.warmup)
-        out["config"]["real_env_steps_logged"] = int(log["total"])
-        out["config"]["final_hand_target_distance"] = float(np.linalg.norm(log["hand"][-1] - log["target"][-1]))
+        out["config"]["real_env_steps_logged"] = log_total
+        out["config"]["final_hand_target_distance"] = log_dist
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

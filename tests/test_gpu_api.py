@@ -55,7 +55,7 @@ def test_reward_types(oracle_sim):
         e.step(a)
 
 
-def test_gather_paths_parallel_schema_and_values(oracle_sim):
+def test_gather_paths_parallel_schema_and_values(oracle_sim, planner_vectors):
     from trajopt import utils
     utils.ROLLOUT_DTYPE = "f64"
     try:
@@ -67,6 +67,7 @@ def test_gather_paths_parallel_schema_and_values(oracle_sim):
         utils.ROLLOUT_DTYPE = "f32"
     assert len(paths) == ppc * ncpu
     assert sorted(paths[0].keys()) == ['actions', 'env_infos', 'next_observations', 'observations', 'rewards', 'states']
+    assert sorted(paths[0].keys()) == list(planner_vectors["g_keys"])      # the keys the reference's paths carry
     raw = ref_mppi.all_raw_normals(500, ppc, ncpu, H, 7)
     act = base + ref_mppi.filter_noise(raw, FILTER)
     R_o, nobs_o, rew_o = oracle_sim.rollout(s["qp"], s["qv"], s["target_pos"], 4, act, dump=True)
@@ -82,6 +83,28 @@ def test_gather_paths_parallel_schema_and_values(oracle_sim):
         assert p["states"][3]["timestep"] == 7 and np.array_equal(p["states"][3]["qp"], p["observations"][3][:7])
     # overlapping worker streams: worker 1 is seeded 5 later, its first sample differs from worker 0's
     assert not np.array_equal(paths[5]["actions"], paths[0]["actions"])
+
+
+def test_try_multiprocess_runs_the_worker_argument_lists(oracle_sim):
+    """`_try_multiprocess(args_list, num_cpu, max_process_time, max_timeouts)` (trajopt/utils.py:166-192): one
+    result list per worker argument list, in worker order; None once the retries are used up (max_timeouts == 0).
+    Here every worker's share is one batched launch in this process."""
+    from trajopt import utils
+    s = dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.0, 0.1]), timestep=2)
+    base = np.zeros((5, 7))
+    args = [['reacher_7dof', s, 3, base, FILTER, 40 + 3 * i, None, 'dense', None, 1.0] for i in range(2)]
+    results = utils._try_multiprocess(args, 2, 300, 4)
+    assert len(results) == 2 and all(len(r) == 3 for r in results)
+    want = base + ref_mppi.filter_noise(ref_mppi.all_raw_normals(40, 3, 2, 5, 7), FILTER)
+    got = np.array([p["actions"] for r in results for p in r])
+    assert np.abs(got - want).max() < 1e-6          # f32 rollouts hand back the fp32 actions they used
+    R_o = oracle_sim.rollout(s["qp"], s["qv"], s["target_pos"], 2, want)
+    R = np.array([p["rewards"].sum() for r in results for p in r])
+    assert np.abs(R - R_o).max() < 1e-4 * np.abs(R_o).max()
+    assert utils._try_multiprocess(args, 2, 300, 0) is None
+    # and gather_paths_parallel is the same samples in the same order
+    paths = utils.gather_paths_parallel('reacher_7dof', s, base, FILTER, 40, None, 'dense', None, 1.0, 3, 2)
+    assert np.array_equal(np.array([p["actions"] for p in paths]), got)
 
 
 def test_do_env_rollout_and_generate_paths(oracle_sim):

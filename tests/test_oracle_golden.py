@@ -155,3 +155,62 @@ def test_shift(planner_vectors, tag, mode):
     for k in range(12):
         seq = ref_mppi.shift(seq, mode, np.array([0.1, 0.2, 0.3]))
         assert np.array_equal(seq, v[tag + "_seqs"][k])
+
+
+# ---- the planner loop restated from ref_mppi pieces, against the reference's own train_step on a toy env ----
+def _toy_rollouts(start_state, acts):
+    """`do_env_rollout` bookkeeping (trajopt/utils.py:72-99) on the toy env: observation, state and info are
+    recorded before every step, reward and next observation after it."""
+    from toy_env import ToyEnv
+    e = ToyEnv()
+    out = []
+    for a in acts:
+        e.set_env_state(start_state)
+        obs, rew, nobs, ts = [], [], [], []
+        for k in range(a.shape[0]):
+            obs.append(e._get_obs())
+            ts.append(e.get_env_infos()["state"]["timestep"])
+            s, r, _, _ = e.step(a[k])
+            rew.append(r)
+            nobs.append(s)
+        out.append((np.array(obs), np.array(rew), np.array(nobs), np.array(ts)))
+    return out
+
+
+def test_gathered_paths_content(planner_vectors):
+    """What `gather_paths_parallel` returned in the reference (toy env, 3 workers x 4 paths): per-path observations,
+    rewards, next observations and info time steps follow from the recorded actions by the bookkeeping above."""
+    from toy_env import ToyEnv
+    v = planner_vectors
+    paths = _toy_rollouts(ToyEnv().get_env_state(), v["g_actions"])
+    assert np.array_equal(np.array([p[0] for p in paths]), v["g_observations"])
+    assert np.array_equal(np.array([p[1] for p in paths]), v["g_rewards"])
+    assert np.array_equal(np.array([p[2] for p in paths]), v["g_next_observations"])
+    assert np.array_equal(np.array([p[3] for p in paths]), v["g_info_timestep"])
+    assert list(v["g_keys"]) == sorted(["observations", "actions", "rewards", "env_infos", "states", "next_observations"])
+
+
+def test_train_step_loop_restatement(planner_vectors):
+    """Three `MPPI.train_step(niter=2)` calls of the reference on the toy env (trajopt/algos/mppi.py:125-196):
+    noise seeded with seed + t and shared by the iterations of a step, score, update, real step with
+    act_sequence[0], shift with the 'mean' tail.  The same loop built from ref_mppi's pieces -- the loop the
+    closed-loop golden data and the acceptance tests are made with -- reproduces it bit for bit."""
+    from toy_env import ToyEnv
+    v = planner_vectors
+    fc = [np.ones(3), 0.25, 0.8, 0.0]
+    e = ToyEnv()
+    state, seq = e.get_env_state(), np.zeros((6, 3))
+    xs, rewards = [state["x"]], []
+    for t in range(3):
+        eps = ref_mppi.filter_noise(ref_mppi.all_raw_normals(77 + t, 8, 1, 6, 3), fc)
+        for _ in range(2):
+            acts = seq + eps
+            R = ref_mppi.score(np.array([p[1] for p in _toy_rollouts(state, acts)]), 0.95)
+            seq = ref_mppi.update(acts, R, 5.0)
+        e.set_env_state(state)
+        _, r, _, _ = e.step(seq[0])
+        state = e.get_env_state()
+        seq = ref_mppi.shift(seq, "mean", np.zeros(3))
+        assert np.array_equal(seq, v["t_seqs"][t])
+        xs.append(state["x"]); rewards.append(r)
+    assert np.array_equal(np.array(rewards), v["t_sol_reward"]) and np.array_equal(np.array(xs), v["t_sol_x"])

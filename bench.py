@@ -232,6 +232,19 @@ def main():
         p.advance_noise(SEED, sptr)
 
     timed = [False]
+    if sharded and not torch_exchange:
+        # first step with the exchange captured in the graph; if the library cannot do it here, every rank fails the
+        # same way and the run continues with the exchange made by torch.distributed (said so in the result line)
+        try:
+            planning_step(0)
+            torch.cuda.synchronize()
+        except Exception as e:             # noqa: BLE001
+            torch_exchange = True
+            exchange = "torch.distributed all-gather between library calls (captured library exchange failed: %s)" % (e,)
+            p.close()
+            p = make_planner(K_local, rank * K_local, local_rank)
+            part = p.partials_tensor()
+            gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
     if torch_exchange:
         p.generate_noise_step(SEED, sptr)
     for i in range(args.warmup):

@@ -1028,6 +1028,10 @@ int mppi_comm_init(mppi_planner* p, const void* id, size_t bytes, int32_t rank, 
     p->d_part_alloc = p->d_part;
     p->d_part = p->d_gathered + row * rank;       // the statistics kernel writes where the gather expects them
     p->comm = comm; p->comm_rank = rank; p->comm_nranks = nranks;
+    // One gather outside any capture: RCCL sets up its connections and buffers at the first collective of a
+    // communicator, which must not happen while a stream is being captured.
+    RCCL_OK(api, api->AllGather(p->d_part, p->d_gathered, row, RCCL_FLOAT64, p->comm, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
     p->cfg_gen++;                   // captured updates were the single-rank kind
     return 0;
 }

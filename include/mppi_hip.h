@@ -40,7 +40,10 @@ enum {
     MPPI_READ_REWARDS = 5,      /* double[K*H]          per-step rewards (needs cfg.dump)               */
     MPPI_READ_STATUS = 6,       /* int32[1]             MPPI_STATUS_* bits, sticky since the planner was created */
     MPPI_READ_RMAX = 7,         /* double[1]            best return                                      */
-    MPPI_READ_PARTIALS = 8      /* double[3+H*M]        this shard's (Rmax, argmax, den, num[H*M])      */
+    MPPI_READ_PARTIALS = 8,     /* double[3+H*M]        this shard's (Rmax, argmax, den, num[H*M])      */
+    MPPI_READ_STATUS_DETAIL = 9 /* int32[4]             status bits; for the first capped solve reported by a     */
+                                /*                      rollout with dumps, a reference or a sparse reward: 1 +    */
+                                /*                      first sample of its wave, env step, planner (else zeros)   */
 };
 
 enum {

@@ -16,7 +16,7 @@ F32, F64 = 0, 1
 REWARD_TYPES = {"dense": 0, "sparse": 1, "tracking": 2, "cooling": 3}
 TAIL = {"repeat": 0, "mean": 1}
 (READ_RETURNS, READ_ACT_SEQ, READ_ARGMAX, READ_ACTIONS, READ_NEXT_OBS, READ_REWARDS, READ_STATUS, READ_RMAX,
- READ_PARTIALS) = range(9)
+ READ_PARTIALS, READ_STATUS_DETAIL) = range(10)
 
 LIB_PATH = os.environ.get("MPPI_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmppi_hip.so")
 

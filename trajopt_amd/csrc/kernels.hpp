@@ -196,6 +196,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     act_rows.reset();
     act_rows.cap = sweep_cap;
     int most_sweeps = 0;
+    int first_capped_step = -1;       // (general kernel variant only) where a capped solve first happened in this wave
     // the next step's noise and base action are fetched one step ahead: they do not depend on the
     // state, and a lone wave has nobody to hide a load's latency behind
     T a[NV];
@@ -219,6 +220,9 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
         }
         Vec3<T> hand;
         const T r = Env<T, MD>::step(q, v, a, rp, rr, hand, act_rows, most_sweeps);
+        if constexpr (!LEAN) {
+            if (first_capped_step < 0 && most_sweeps > sweep_cap) first_capped_step = t;
+        }
         // with a terminal-value critic the last reward is replaced by the critic's value (added by critic_kernel)
         if (!(fobs && t == H - 1)) ret += g * r;
         g *= gm;
@@ -241,7 +245,16 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     }
     R[k] = ret;
     if (nonfinite(ret)) atomicOr(status, MPPI_STATUS_NONFINITE);
-    if (most_sweeps > sweep_cap) atomicOr(status, MPPI_STATUS_SWEEP_CAP);
+    if (most_sweeps > sweep_cap) {
+        const int before = atomicOr(status, MPPI_STATUS_SWEEP_CAP);
+        if constexpr (!LEAN) {
+            // the first lane to report leaves where it happened: [1] first sample of the wave, [2] env step, [3] planner
+            if (!(before & MPPI_STATUS_SWEEP_CAP) && atomicCAS(status + 1, 0, (int)(blockIdx.x * blockDim.x) + 1) == 0) {
+                status[2] = first_capped_step;
+                status[3] = (int)blockIdx.y;
+            }
+        }
+    }
 }
 
 // one fp64 env.step of the real environment; io: in [q(nq) v(nv) target(3) act(nv) alpha refrow(3)],

@@ -343,8 +343,8 @@ static int planner_allocate(mppi_planner* p) {
     HIP_OK(hipMemset(p->d_part, 0, (3 * P + HM) * 8));
     HIP_OK(hipMalloc(&p->d_result, 2 * 8 * P));
     HIP_OK(hipMemset(p->d_result, 0, 2 * 8 * P));
-    HIP_OK(hipMalloc(&p->d_status, 4));
-    HIP_OK(hipMemset(p->d_status, 0, 4));
+    HIP_OK(hipMalloc(&p->d_status, 16));
+    HIP_OK(hipMemset(p->d_status, 0, 16));
     HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (p->nq + 2 * p->nv + 7) * 8));
     HIP_OK(hipMalloc(&p->d_log_count, 4 * P));
     HIP_OK(hipMemset(p->d_log_count, 0, 4 * P));
@@ -930,6 +930,10 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) {
     case MPPI_READ_STATUS:
         if (!need(4)) return fail(-1, "STATUS needs one int32");
         HIP_OK(hipMemcpy(dst, p->d_status, 4, hipMemcpyDeviceToHost));
+        return 0;
+    case MPPI_READ_STATUS_DETAIL:
+        if (!need(16)) return fail(-1, "STATUS_DETAIL needs four int32");
+        HIP_OK(hipMemcpy(dst, p->d_status, 16, hipMemcpyDeviceToHost));
         return 0;
     case MPPI_READ_PARTIALS:
         if (!need(P * (3 + HM) * 8)) return fail(-1, "PARTIALS needs P*(3+H*M) doubles");

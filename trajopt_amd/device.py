@@ -286,5 +286,9 @@ class DevicePlanner:
     def status(self):
         return int(self._read(L.READ_STATUS, (1,), np.int32)[0])
 
+    def status_detail(self):
+        """(bits, first sample of the wave + 1, env step, planner) of the first capped solve a general-variant rollout reported."""
+        return [int(x) for x in self._read(L.READ_STATUS_DETAIL, (4,), np.int32)]
+
     def partials(self):
         return self._read(L.READ_PARTIALS, self._lead(3 + self.H * self.nv))

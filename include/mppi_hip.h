@@ -6,7 +6,10 @@
  * holds the prototypes and structure layouts of such a binding.
  *
  * Conventions: every function returns 0 on success and a negative code on
- * failure; the message is available from mppi_last_error() (thread local,
+ * failure (-1 bad argument, -2 HIP error, -3 no kernel for the model, -4 wrong
+ * state for the call, -5 reference index out of range, -6 size limit, -7 RCCL
+ * error, -8 host exception such as out of memory; nothing is thrown across
+ * this boundary); the message is available from mppi_last_error() (thread local,
  * valid until the next call on that thread).  Host pointers are copied before
  * the call returns.  `stream` arguments take a hipStream_t (or NULL for the
  * planner's own stream).  A planner is not re-entrant; distinct planners may

@@ -369,7 +369,7 @@ extern "C" {
 int mppi_version(void) { return MPPI_ABI_VERSION; }
 const char* mppi_last_error(void) { return g_err.c_str(); }
 
-int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) {
+int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) try {
     if (!desc || !out) return fail(-1, "null argument");
     std::string why = "unknown model name";
     for (const ModelOps* op : g_ops) {
@@ -384,6 +384,8 @@ int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) {
         return 0;
     }
     return fail(-3, std::string("no kernel compiled for model '") + std::string(desc->name, strnlen(desc->name, 64)) + "'");
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 void mppi_model_destroy(mppi_model* m) {
@@ -393,7 +395,7 @@ void mppi_model_destroy(mppi_model* m) {
     delete m;
 }
 
-int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_planner** out) {
+int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_planner** out) try {
     if (!m || !cfg || !out) return fail(-1, "null argument");
     if (cfg->K < 1 || cfg->H < 1) return fail(-1, "K and H must be positive");
     if (cfg->dtype != MPPI_F32 && cfg->dtype != MPPI_F64) return fail(-1, "dtype must be MPPI_F32 or MPPI_F64");
@@ -428,6 +430,8 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     }
     *out = p;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 void mppi_planner_destroy(mppi_planner* p) {
@@ -453,7 +457,7 @@ void mppi_planner_destroy(mppi_planner* p) {
 }
 
 int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel, const double* target3,
-                         const int32_t* timestep) {
+                         const int32_t* timestep) try {
     if (!p || !qpos || !qvel || !target3 || !timestep) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     // alpha / ref_len come from the host mirror; q, v, target, timestep are replaced
@@ -468,17 +472,21 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
     HIP_OK(hipStreamSynchronize(p->stream));
     p->noise_ahead = false;          // the stream key follows the timestep
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_set_base_actions(mppi_planner* p, const double* act) {
+int mppi_set_base_actions(mppi_planner* p, const double* act) try {
     if (!p || !act) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipMemcpyAsync(p->d_base, act, (size_t)p->HM * p->P * 8, hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alpha) {
+int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alpha) try {
     if (!p) return fail(-1, "null argument");
     if (T < 0 || (T > 0 && !ref)) return fail(-1, "bad reference");
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -499,10 +507,12 @@ int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alp
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(p->stream));      // the caller may reuse its buffer
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1, const float* b1, const float* W2,
-                    const float* b2, const float* W3, float b3) {
+                    const float* b2, const float* W3, float b3) try {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
@@ -523,17 +533,21 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
     if (p->critic_dim != dim) p->cfg_gen++;       // the weights are read at run time; the input slice is an argument
     p->critic_dim = dim;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_type) {
+int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_type) try {
     if (!p) return fail(-1, "null argument");
     if (reward_type < 0 || reward_type > 3) return fail(-1, "bad reward_type");
     if (p->cfg.kappa != kappa || p->cfg.gamma != gamma || p->cfg.reward_type != reward_type) p->cfg_gen++;
     p->cfg.kappa = kappa; p->cfg.gamma = gamma; p->cfg.reward_type = reward_type;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) {
+int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) try {
     if (!p || !raw) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
@@ -544,6 +558,8 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) {
     p->explicit_act = 0;
     p->noise_ahead = false;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 static int generate_noise(mppi_planner* p, uint64_t seed, int seed_from_state, void* stream) {
@@ -558,16 +574,18 @@ static int generate_noise(mppi_planner* p, uint64_t seed, int seed_from_state, v
 int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream) { return generate_noise(p, seed, 0, stream); }
 int mppi_generate_noise_step(mppi_planner* p, uint64_t seed, void* stream) { return generate_noise(p, seed, 1, stream); }
 
-int mppi_advance(mppi_planner* p, void* stream) {
+int mppi_advance(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
                                   p->d_log, MPPI_LOG_CAP, p->d_log_count, pick(p, stream)));
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) {
+int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance_noise");
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -578,9 +596,11 @@ int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) {
     p->noise_ahead = true;
     p->noise_ahead_seed = seed;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total) {
+int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total) try {
     if (!p || !rows || !n_rows || max_rows < 0 || planner < 0 || planner >= p->P) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
@@ -599,9 +619,11 @@ int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_ro
     *n_rows = n;
     if (total) *total = count;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) {
+int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) try {
     if (!p || !act) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
@@ -612,6 +634,8 @@ int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) {
     p->explicit_act = 1;
     p->noise_ahead = false;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
@@ -680,13 +704,15 @@ static int launch_merge(mppi_planner* p, const double* gathered, int nranks, hip
     return 0;
 }
 
-int mppi_rollout(mppi_planner* p, void* stream) {
+int mppi_rollout(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     return launch_rollout_only(p, pick(p, stream));
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_local_partials(mppi_planner* p, void* stream) {
+int mppi_local_partials(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -694,19 +720,25 @@ int mppi_local_partials(mppi_planner* p, void* stream) {
     int rc = launch_rollout_only(p, s);
     if (rc) return rc;
     return launch_partials(p, s);
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_partials_ptr(mppi_planner* p, void** ptr, size_t* bytes) {
+int mppi_partials_ptr(mppi_planner* p, void** ptr, size_t* bytes) try {
     if (!p || !ptr || !bytes) return fail(-1, "null argument");
     *ptr = p->d_part;
     *bytes = (size_t)(3 + p->HM) * p->P * 8;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_merge(mppi_planner* p, const void* gathered, int32_t nranks, void* stream) {
+int mppi_merge(mppi_planner* p, const void* gathered, int32_t nranks, void* stream) try {
     if (!p || !gathered || nranks < 1) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     return launch_merge(p, (const double*)gathered, nranks, pick(p, stream));
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 static int build_graph(mppi_planner* p) {
@@ -725,7 +757,7 @@ static int build_graph(mppi_planner* p) {
     return 0;
 }
 
-int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
+int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) try {
     if (!p || niter < 0) return fail(-1, "bad argument");
     if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -742,6 +774,8 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) {
         if (rc) return rc;
     }
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 // one whole planning step enqueued on s (no host synchronisation)
@@ -772,7 +806,7 @@ static int enqueue_plan_noise(mppi_planner* p, uint64_t seed, hipStream_t s) {
     return 0;
 }
 
-int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream) {
+int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream) try {
     if (!p || niter < 1 || nsteps < 0) return fail(-1, "bad argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_plan");
     if (nsteps == 0) return 0;
@@ -812,9 +846,11 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
     p->noise_ahead = ahead;
     p->noise_ahead_seed = seed;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) {
+int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) try {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
@@ -827,15 +863,19 @@ int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) {
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(p->d_base, p->d_base_tmp, (size_t)p->HM * p->P * 8, hipMemcpyDeviceToDevice, s));
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_profile(mppi_planner* p, int32_t enable) {
+int mppi_profile(mppi_planner* p, int32_t enable) try {
     if (!p) return fail(-1, "null argument");
     p->profiling = enable != 0;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_profile_read(mppi_planner* p, double* rollout_ms_total, int32_t* launches) {
+int mppi_profile_read(mppi_planner* p, double* rollout_ms_total, int32_t* launches) try {
     if (!p || !rollout_ms_total || !launches) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     double total = 0.0;
@@ -853,13 +893,17 @@ int mppi_profile_read(mppi_planner* p, double* rollout_ms_total, int32_t* launch
     *rollout_ms_total = total;
     *launches = n;
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_synchronize(mppi_planner* p) {
+int mppi_synchronize(mppi_planner* p) try {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 static int read_as_double(mppi_planner* p, const void* dsrc, size_t n, double* dst) {
@@ -873,7 +917,7 @@ static int read_as_double(mppi_planner* p, const void* dsrc, size_t n, double* d
     return 0;
 }
 
-int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) {
+int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) try {
     if (!p || !dst) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));
@@ -941,6 +985,8 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) {
         return 0;
     }
     return fail(-1, "unknown read selector");
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 static int env_io(const mppi_model* m, int device, double** io) {
@@ -954,7 +1000,7 @@ static int env_io(const mppi_model* m, int device, double** io) {
 
 int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const double* qvel, const double* target3,
                   const double* act, int32_t timestep, int32_t reward_type, const double* ref, int32_t T, double alpha,
-                  double* qpos_out, double* qvel_out, double* obs_out, double* reward_out) {
+                  double* qpos_out, double* qvel_out, double* obs_out, double* reward_out) try {
     if (!m || !qpos || !qvel || !target3 || !act) return fail(-1, "null argument");
     if ((reward_type == MPPI_REWARD_TRACKING || reward_type == MPPI_REWARD_COOLING) && (!ref || T < 1))
         return fail(-1, "tracking / cooling reward needs a reference");
@@ -982,9 +1028,11 @@ int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const
     if (obs_out) for (int i = 0; i < ns + 6; i++) obs_out[i] = out[ns + i];
     if (reward_out) *reward_out = out[2 * ns + 6];
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, double* hand3_out) {
+int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, double* hand3_out) try {
     if (!m || !qpos || !hand3_out) return fail(-1, "null argument");
     const int nv = m->ops->nv, nq = m->ops->nq, ns = nq + nv;
     double* io;
@@ -998,18 +1046,22 @@ int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, do
     HIP_OK(hipMemcpy(out, io + 256, (2 * ns + 7) * 8, hipMemcpyDeviceToHost));
     for (int c = 0; c < 3; c++) hand3_out[c] = out[2 * ns + c];
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_comm_unique_id(void* id_out, size_t bytes) {
+int mppi_comm_unique_id(void* id_out, size_t bytes) try {
     if (!id_out || bytes != sizeof(RcclUniqueId)) return fail(-1, "the exchange id is 128 bytes");
     std::string why;
     const RcclApi* api = rccl_api(why);
     if (!api) return fail(-7, why);
     RCCL_OK(api, api->GetUniqueId((RcclUniqueId*)id_out));
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
-int mppi_comm_init(mppi_planner* p, const void* id, size_t bytes, int32_t rank, int32_t nranks) {
+int mppi_comm_init(mppi_planner* p, const void* id, size_t bytes, int32_t rank, int32_t nranks) try {
     if (!p || !id || bytes != sizeof(RcclUniqueId)) return fail(-1, "bad argument (the exchange id is 128 bytes)");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "rank must lie in [0, nranks)");
     if (p->comm) return fail(-4, "the planner already has an exchange");
@@ -1038,10 +1090,12 @@ int mppi_comm_init(mppi_planner* p, const void* id, size_t bytes, int32_t rank, 
     HIP_OK(hipStreamSynchronize(p->stream));
     p->cfg_gen++;                   // captured updates were the single-rank kind
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 int mppi_update_from_returns(int32_t device, const double* act, const double* R, int32_t K, int32_t HM, double kappa,
-                             double* act_seq_out) {
+                             double* act_seq_out) try {
     if (!act || !R || !act_seq_out || K < 1 || HM < 1) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(device));
     struct Owned {            // released on every way out
@@ -1057,10 +1111,12 @@ int mppi_update_from_returns(int32_t device, const double* act, const double* R,
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpy(act_seq_out, d_out.p, (size_t)HM * 8, hipMemcpyDeviceToHost));
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 int mppi_update_from_returns_noalloc(int32_t device, const double* d_act, const double* d_R, int32_t K, int32_t HM,
-                                     double kappa, double* d_act_seq_out, void* stream) {
+                                     double kappa, double* d_act_seq_out, void* stream) try {
     if (!d_act || !d_R || !d_act_seq_out || K < 1 || HM < 1) return fail(-1, "bad argument");
     if (K > MPPI_NOALLOC_MAX_K)
         return fail(-6, "mppi_update_from_returns_noalloc: K = " + std::to_string(K) + " exceeds the fixed workspace of " +
@@ -1076,6 +1132,8 @@ int mppi_update_from_returns_noalloc(int32_t device, const double* d_act, const 
     hipLaunchKernelGGL(noalloc_sum_kernel, dim3(HM), dim3(256), 0, s, d_act, (const double*)ws, (int)K, (int)HM, d_act_seq_out);
     HIP_OK(hipGetLastError());
     return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -96,7 +97,7 @@ template <class F> void parallel_for(int nthreads, size_t n, F&& body) {       /
 // state_out (may be null) receives what np.random.get_state() would show afterwards: 624 key words, position,
 // has_gauss, and the cached variate as raw bits -- 628 words -- so that a caller can leave the process-global numpy
 // generator exactly where the reference's in-process worker leaves it.
-extern "C" int mppi_numpy_normals(uint32_t seed, size_t n, double* out, int32_t nthreads, uint32_t* state_out) {
+extern "C" int mppi_numpy_normals(uint32_t seed, size_t n, double* out, int32_t nthreads, uint32_t* state_out) try {
     if (!out && n) return -1;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
@@ -163,4 +164,6 @@ extern "C" int mppi_numpy_normals(uint32_t seed, size_t n, double* out, int32_t 
         std::memcpy(&state_out[626], &g, 8);
     }
     return 0;
+} catch (const std::exception&) {
+    return -8;          // out of host memory (or no thread could be started)
 }

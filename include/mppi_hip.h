@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define MPPI_MAXV 32
-#define MPPI_ABI_VERSION 5
+#define MPPI_ABI_VERSION 6
 #define MPPI_LOG_CAP 4096
 #define MPPI_NOALLOC_MAX_K 262144   /* most samples mppi_update_from_returns_noalloc accepts */
 
@@ -156,6 +156,11 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
  * mode; the sigma scaling and the recursive filter run on the device.
  * generate: counter-based Philox-4x32-10 stream keyed by seed, counter = global sample index. */
 int mppi_upload_noise(mppi_planner* p, const double* raw_KxHxM, void* stream);
+/* A page-locked host buffer of P*K*H*M doubles that belongs to the planner (made on the first call, freed with the
+ * planner): the place to write the draws of `np.random.normal(size=(H, m))` (trajopt/utils.py:120) for
+ * mppi_upload_noise / mppi_upload_actions, which copy from it at the bus rate instead of the pageable-memory rate.
+ * The uploads return after the copy, so the buffer may be rewritten as soon as they have returned. */
+int mppi_host_staging(mppi_planner* p, double** buffer_out);
 int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream);
 /* Same, with the stream key = seed + the planner's current timestep read on the device: the
  * reference re-seeds every planning step with `self.seed + t` (trajopt/algos/mppi.py:130-132). */
@@ -254,6 +259,9 @@ int mppi_update_from_returns_noalloc(int32_t device, const double* d_act_KxHM, c
  * threads (several times faster than numpy's one-value-at-a-time generator).  state_out, if not NULL, receives 628
  * words: what np.random.get_state() would hold afterwards (key[624], pos, has_gauss, cached variate as two words). */
 int mppi_numpy_normals(uint32_t seed, size_t n, double* out, int32_t nthreads, uint32_t* state_out);
+/* The streams of several pool workers side by side (trajopt/utils.py:151-163: worker i re-seeds its own generator with
+ * seeds[i]): n_each values per stream into out + i * n_each, the threads shared between the streams. */
+int mppi_numpy_normals_many(const uint32_t* seeds, int32_t nstreams, size_t n_each, double* out, int32_t nthreads);
 
 /* Philox-4x32-10 block function (host), for known-answer tests of the device generator. */
 void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -222,3 +222,29 @@ def test_status_reports_a_capped_active_set_solve(dm, oracle_sim):
     eps = ref_mppi.filter_noise(raw.copy(), FILTER)
     R_o = oracle_sim.rollout(q0, np.zeros(7), np.zeros(3), 0, eps)
     assert np.abs(got[0][1] - R_o).max() / np.abs(R_o).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_page_locked_staging_uploads_like_any_host_array(dm):
+    """The planner's own host buffer (mppi_host_staging) is a faster source for uploads, nothing else: same noise,
+    same returns, same memory at every call, and rewriting it after an upload does not disturb the upload."""
+    from trajopt_amd.device import DevicePlanner
+    from trajopt_amd.utils import all_worker_normals
+    K, H = 96, 8
+    a = DevicePlanner(dm, K, H, dtype="f64", dump=True)
+    b = DevicePlanner(dm, K, H, dtype="f64", dump=True)
+    raw = all_worker_normals(3, 48, 2, H, 7)
+    buf = a.host_staging()
+    assert buf.shape == (K, H, 7) and buf.dtype == np.float64 and a.host_staging() is buf
+    got = all_worker_normals(3, 48, 2, H, 7, out=buf)
+    assert got is buf and np.array_equal(buf, raw)
+    for p, src in ((a, buf), (b, raw)):
+        p.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, 0.0, 0.1]), 0)
+        p.set_base_actions(np.zeros((H, 7)))
+        p.upload_noise(src)
+    buf[:] = 0.0
+    for p in (a, b):
+        p.rollout()
+    assert np.array_equal(a.actions(), b.actions()) and np.array_equal(a.returns(), b.returns())
+    assert np.abs(a.actions()).max() > 0
+    a.close(); b.close()

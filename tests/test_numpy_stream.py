@@ -13,7 +13,8 @@ def _ours(seed, n, threads, want_state=True):
 
 
 @pytest.mark.parametrize("seed,n,threads", [(0, 1, 1), (1, 2, 1), (123, 7, 2), (12345, 3584, 1), (2, 4481, 3),
-                                            (2 ** 32 - 1, 1001, 4), (77, 100000, 8), (5, 250001, 16), (9, 0, 1)])
+                                            (2 ** 32 - 1, 1001, 4), (77, 100000, 8), (5, 250001, 16), (9, 0, 1),
+                                            (11, 1000001, 8), (3, 600000, 1), (4, 700000, 2)])   # the last three wrap the generator's ring
 def test_stream_and_state_equal_numpy(seed, n, threads):
     got, state = _ours(seed, n, threads)
     np.random.seed(seed)
@@ -55,5 +56,18 @@ def test_random_seeds_and_lengths():
     rs = np.random.RandomState(0)
     for _ in range(40):
         seed, n, th = int(rs.randint(0, 2 ** 31)), int(rs.randint(1, 30000)), int(rs.randint(1, 9))
-        got, _ = _ours(seed, n, th, want_state=False)
-        assert np.array_equal(got, np.random.RandomState(seed).normal(size=n)), (seed, n, th)
+        got, state = _ours(seed, n, th)
+        ref = np.random.RandomState(seed)
+        assert np.array_equal(got, ref.normal(size=n)), (seed, n, th)
+        _, key, pos, has_gauss, cached = ref.get_state()
+        assert np.array_equal(state[:624], key) and (int(state[624]), int(state[625])) == (pos, has_gauss), (seed, n, th)
+
+
+@pytest.mark.parametrize("streams,n_each,threads", [(8, 40001, 4), (3, 300000, 8), (20, 1000, 3), (1, 5000, 2), (0, 10, 2)])
+def test_several_worker_streams_side_by_side(streams, n_each, threads):
+    from trajopt_amd import _lib as L
+    seeds = np.array([7 + 13 * i for i in range(streams)], dtype=np.uint32)
+    out = np.full(streams * n_each, np.nan)
+    assert L.lib().mppi_numpy_normals_many(L.ptr(seeds), streams, n_each, L.ptr(out), threads) == 0
+    for i in range(streams):
+        assert np.array_equal(out[i * n_each:(i + 1) * n_each], np.random.RandomState(int(seeds[i])).normal(size=n_each)), i

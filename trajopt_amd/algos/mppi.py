@@ -170,7 +170,7 @@ class MPPI(Trajectory):
         if self.noise == 'philox':
             p.generate_noise(seed)
         else:
-            p.upload_noise(all_worker_normals(seed, self.paths_per_cpu, self.num_cpu, H, self.m))
+            p.upload_noise(all_worker_normals(seed, self.paths_per_cpu, self.num_cpu, H, self.m, out=p.host_staging()))
         p.iterate(niter)
         self.act_sequence = p.act_sequence()
 

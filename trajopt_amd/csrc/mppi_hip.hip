@@ -282,6 +282,7 @@ struct mppi_planner {
     double* d_mean;
     void* d_eps;           // T [H][M][K]
     double* d_raw;         // staging for host uploads [K][H][M]
+    double* h_stage;       // page-locked host buffer of the same size, made on request
     double* d_ref;
     int ref_cap;
     void* d_R;             // T [K]
@@ -448,6 +449,7 @@ void mppi_planner_destroy(mppi_planner* p) {
         if (const RcclApi* api = rccl_api(why)) (void)api->CommDestroy(p->comm);
     }
     if (p->d_gathered) (void)hipFree(p->d_gathered);
+    if (p->h_stage) (void)hipHostFree(p->h_stage);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R,
                     p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
     for (void* b : bufs)
@@ -542,6 +544,16 @@ int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_
     if (reward_type < 0 || reward_type > 3) return fail(-1, "bad reward_type");
     if (p->cfg.kappa != kappa || p->cfg.gamma != gamma || p->cfg.reward_type != reward_type) p->cfg_gen++;
     p->cfg.kappa = kappa; p->cfg.gamma = gamma; p->cfg.reward_type = reward_type;
+    return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
+}
+
+int mppi_host_staging(mppi_planner* p, double** out) try {
+    if (!p || !out) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    if (!p->h_stage) HIP_OK(hipHostMalloc(&p->h_stage, (size_t)p->HM * p->cfg.K * p->P * 8, hipHostMallocDefault));
+    *out = p->h_stage;
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());

@@ -99,12 +99,14 @@ class DevicePlanner:
         self._ref_sent = (None, None)       # what the device holds: calls that would not change it are skipped
         self._critic_sent = None
         self._h = L._vp()
+        self._staging = None
         L.check(L.lib().mppi_planner_create(model._h, C.byref(cfg), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None):
             L.lib().mppi_planner_destroy(self._h)
             self._h = None
+            self._staging = None            # the memory behind it is gone
 
     def __del__(self):
         try:
@@ -156,6 +158,17 @@ class DevicePlanner:
         L.check(L.lib().mppi_set_critic(self._h, int(dim), int(inner), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
                                         L.ptr(W3), float(b3.reshape(-1)[0])))
         self._critic_sent = sent
+
+    def host_staging(self):
+        """The planner's page-locked host buffer as a (K, H, m) float64 array (leading P for batches): draws written
+        here upload at the bus rate.  The same memory at every call; it dies with the planner."""
+        if self._staging is None:
+            ptr = C.c_void_p()
+            L.check(L.lib().mppi_host_staging(self._h, C.byref(ptr)))
+            shape = self._lead(self.K, self.H, self.nv)
+            n = int(np.prod(shape))
+            self._staging = np.ctypeslib.as_array((C.c_double * n).from_address(ptr.value)).reshape(shape)
+        return self._staging
 
     def upload_noise(self, raw):
         raw = L.f64(raw)

@@ -217,19 +217,22 @@ def _host_threads():
     return _HOST_THREADS
 
 
-def worker_normals(base_seed, n_paths, H, m, in_process=True):
+def worker_normals(base_seed, n_paths, H, m, in_process=True, out=None):
     """Raw N(0,1) draws of one reference worker: seed once, then n_paths blocks of (H, m) in
     order (`generate_paths`, trajopt/utils.py:135-139) -- numpy's legacy stream, produced in bulk by the
     library's generator (same bits as `np.random.seed(base_seed)` + `np.random.normal(size=(H, m))` calls).
     in_process: the worker is the calling process itself (the reference's num_cpu == 1 path,
     trajopt/utils.py:171-172), which leaves the process-global numpy generator re-seeded and advanced past the
     draws: the global state is set to exactly that.  Pool workers re-seed only their own copy, so with several
-    workers the caller's generator is left alone."""
+    workers the caller's generator is left alone.
+    out: a C-contiguous float64 array of shape (n_paths, H, m) to fill instead of a new one."""
     from . import _lib as L
     seed = int(base_seed)
     if not 0 <= seed < 2 ** 32:
         raise ValueError("Seed must be between 0 and 2**32 - 1")
-    out = np.empty((n_paths, H, m))
+    if out is None:
+        out = np.empty((n_paths, H, m))
+    assert out.shape == (n_paths, H, m) and out.dtype == np.float64 and out.flags.c_contiguous
     state = np.empty(628, dtype=np.uint32) if in_process else None
     rc = L.lib().mppi_numpy_normals(seed, out.size, L.ptr(out), _host_threads(), L.ptr(state))
     if rc != 0:
@@ -239,11 +242,23 @@ def worker_normals(base_seed, n_paths, H, m, in_process=True):
     return out
 
 
-def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m):
+def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m, out=None):
     """(K, H, m) draws in global sample order k = worker * paths_per_cpu + j, worker i seeded
-    with base_seed + i * paths_per_cpu (trajopt/utils.py:151-152: overlapping streams)."""
-    return np.concatenate([worker_normals(base_seed + i * paths_per_cpu, paths_per_cpu, H, m, in_process=(num_cpu == 1))
-                           for i in range(num_cpu)])
+    with base_seed + i * paths_per_cpu (trajopt/utils.py:151-152: overlapping streams).
+    out: a (K, H, m) float64 array to fill (a planner's page-locked staging buffer) instead of a new one."""
+    if out is None:
+        out = np.empty((paths_per_cpu * num_cpu, H, m))
+    assert out.shape == (paths_per_cpu * num_cpu, H, m) and out.dtype == np.float64 and out.flags.c_contiguous
+    if num_cpu == 1:
+        return worker_normals(base_seed, paths_per_cpu, H, m, in_process=True, out=out)
+    from . import _lib as L
+    seeds = [int(base_seed) + i * paths_per_cpu for i in range(num_cpu)]
+    if not all(0 <= s < 2 ** 32 for s in seeds):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    seeds = np.array(seeds, dtype=np.uint32)
+    if L.lib().mppi_numpy_normals_many(L.ptr(seeds), num_cpu, paths_per_cpu * H * m, L.ptr(out), _host_threads()) != 0:
+        raise RuntimeError("mppi_numpy_normals_many failed")
+    return out
 
 
 def generate_paths(env_name, start_state, N, base_act, filter_coefs, base_seed, goal, reward_type, reference, alpha):
@@ -269,7 +284,6 @@ def gather_paths_parallel(env_name, start_state, base_act, filter_coefs, base_se
     K = paths_per_cpu * num_cpu
     reward_type, reference = rollout_objective(env_name, reward_type, reference)
     _check_reference(reward_type, reference, int(start_state['timestep']), H)
-    raw = all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m)
     sigma, b0, b1, b2 = filter_coefs
     key = (env_name, K, H, ROLLOUT_DTYPE, 'noise', tuple(np.broadcast_to(np.asarray(sigma, float), (m,))), b0, b1, b2)
     p = _PLANNERS.get(key)
@@ -283,7 +297,7 @@ def gather_paths_parallel(env_name, start_state, base_act, filter_coefs, base_se
     p.set_start_state(start_state['qp'], start_state['qv'], start_state['target_pos'], start_state['timestep'])
     p.set_reference(reference if reward_type in ('tracking', 'cooling') else None, 1.0 if alpha is None else alpha)
     p.set_base_actions(base_act)
-    p.upload_noise(raw)
+    p.upload_noise(all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m, out=p.host_staging()))
     p.rollout()
     return _paths_from_device(p, start_state, p.actions(), env_name)
 

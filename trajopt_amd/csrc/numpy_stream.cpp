@@ -2,9 +2,11 @@
 // `np.random.normal(size=...)` calls yields (MT19937 seeded by the Knuth recurrence, 53-bit doubles from two outputs,
 // polar Box-Muller with the second variate of a pair cached for the next draw).  The reference's rollout workers
 // draw their perturbations from exactly this stream (trajopt/utils.py:118-139); the planner's exact-comparison noise
-// mode uploads it.  numpy makes the stream one value at a time; here the generator runs ahead in bulk and the
-// logarithms and square roots of the accepted pairs are spread over threads.  Same libm, same operation order:
+// mode uploads it.  numpy makes the stream one value at a time; here one thread runs the generator's recurrence ahead
+// in bulk (vector instructions, state blocks written straight into a ring) and the other threads follow behind it
+// with the tempering, the rejection test, the logarithms and the square roots.  Same libm, same operation order:
 // same bits (tests compare against numpy itself).
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -23,87 +25,99 @@
 namespace {
 
 typedef uint32_t u32x8 __attribute__((vector_size(32), aligned(4)));
+typedef uint32_t u32x16 __attribute__((vector_size(64), aligned(4)));
 constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MAT = 0x9908b0dfu;
+constexpr int NW = 624;                 // words of generator state = outputs per regeneration
 
 inline uint32_t twist(uint32_t a, uint32_t b, uint32_t far) {
     const uint32_t y = (a & UP) | (b & LO);
     return far ^ (y >> 1) ^ ((0u - (y & 1u)) & MAT);
 }
-// One regeneration of the 624-word state, eight words at a time: word i needs the old words i, i+1 and word
-// i+397 (mod 624), which is old for i < 227 and otherwise was rewritten 227 positions earlier, so blocks of eight
-// never read a word of their own block's making.  `out` receives the tempered words.
-#define MT_REFILL_BODY(LOAD, STORE)                                                                            \
+
+// The state after `prev`, W words at a time: word i needs words i and i+1 of the old state and word i+397 (mod 624),
+// which is old for i < 227 and otherwise is word i-227 of the new state, made at least 227 positions earlier, so a
+// group of W never reads a word of its own making.
+#define MT_NEXT_BODY(VEC, W)                                                                                   \
     int i = 0;                                                                                                 \
-    for (; i + 8 <= 227; i += 8) {                                                                             \
-        const u32x8 a = LOAD(key + i), b = LOAD(key + i + 1), f = LOAD(key + i + 397);                         \
-        const u32x8 y = (a & UP) | (b & LO);                                                                   \
-        STORE(key + i, f ^ (y >> 1) ^ ((0u - (y & 1u)) & MAT));                                                \
+    for (; i + W <= 227; i += W) {                                                                             \
+        const VEC a = *(const VEC*)(prev + i), b = *(const VEC*)(prev + i + 1), f = *(const VEC*)(prev + i + 397); \
+        const VEC y = (a & UP) | (b & LO);                                                                     \
+        *(VEC*)(next + i) = f ^ (y >> 1) ^ ((0u - (y & 1u)) & MAT);                                            \
     }                                                                                                          \
-    for (; i < 227; i++) key[i] = twist(key[i], key[i + 1], key[i + 397]);                                     \
-    for (; i + 8 <= 623; i += 8) {                                                                             \
-        const u32x8 a = LOAD(key + i), b = LOAD(key + i + 1), f = LOAD(key + i - 227);                         \
-        const u32x8 y = (a & UP) | (b & LO);                                                                   \
-        STORE(key + i, f ^ (y >> 1) ^ ((0u - (y & 1u)) & MAT));                                                \
+    for (; i < 227; i++) next[i] = twist(prev[i], prev[i + 1], prev[i + 397]);                                 \
+    for (; i + W <= 623; i += W) {                                                                             \
+        const VEC a = *(const VEC*)(prev + i), b = *(const VEC*)(prev + i + 1), f = *(const VEC*)(next + i - 227); \
+        const VEC y = (a & UP) | (b & LO);                                                                     \
+        *(VEC*)(next + i) = f ^ (y >> 1) ^ ((0u - (y & 1u)) & MAT);                                            \
     }                                                                                                          \
-    for (; i < 623; i++) key[i] = twist(key[i], key[i + 1], key[i - 227]);                                     \
-    key[623] = twist(key[623], key[0], key[396]);                                                              \
-    for (i = 0; i + 8 <= 624; i += 8) {                                                                        \
-        u32x8 y = LOAD(key + i);                                                                               \
+    for (; i < 623; i++) next[i] = twist(prev[i], prev[i + 1], next[i - 227]);                                 \
+    next[623] = twist(prev[623], next[0], next[396]);
+
+#define MT_TEMPER_BODY(VEC, W)                                                                                 \
+    size_t i = 0;                                                                                              \
+    for (; i + W <= n; i += W) {                                                                               \
+        VEC y = *(const VEC*)(w + i);                                                                          \
         y ^= y >> 11;                                                                                          \
         y ^= (y << 7) & 0x9d2c5680u;                                                                           \
         y ^= (y << 15) & 0xefc60000u;                                                                          \
         y ^= y >> 18;                                                                                          \
-        STORE(out + i, y);                                                                                     \
+        *(VEC*)(w + i) = y;                                                                                    \
+    }                                                                                                          \
+    for (; i < n; i++) {                                                                                       \
+        uint32_t y = w[i];                                                                                     \
+        y ^= y >> 11;                                                                                          \
+        y ^= (y << 7) & 0x9d2c5680u;                                                                           \
+        y ^= (y << 15) & 0xefc60000u;                                                                          \
+        y ^= y >> 18;                                                                                          \
+        w[i] = y;                                                                                              \
     }
 
-#define load8(p) (*reinterpret_cast<const u32x8*>(p))
-#define store8(p, v) (*reinterpret_cast<u32x8*>(p) = (v))
+__attribute__((target("avx512f"))) void next_state_512(const uint32_t* prev, uint32_t* next) { MT_NEXT_BODY(u32x16, 16) }
+__attribute__((target("avx2"))) void next_state_256(const uint32_t* prev, uint32_t* next) { MT_NEXT_BODY(u32x8, 8) }
+void next_state_base(const uint32_t* prev, uint32_t* next) { MT_NEXT_BODY(u32x8, 8) }
+__attribute__((target("avx512f"))) void temper_512(uint32_t* w, size_t n) { MT_TEMPER_BODY(u32x16, 16) }
+__attribute__((target("avx2"))) void temper_256(uint32_t* w, size_t n) { MT_TEMPER_BODY(u32x8, 8) }
+void temper_base(uint32_t* w, size_t n) { MT_TEMPER_BODY(u32x8, 8) }
 
-__attribute__((target("avx2"))) void refill_tempered_avx2(uint32_t* key, uint32_t* out) { MT_REFILL_BODY(load8, store8) }
-void refill_tempered_base(uint32_t* key, uint32_t* out) { MT_REFILL_BODY(load8, store8) }
-
-struct MT19937 {
-    uint32_t key[624];
-    uint32_t block[624];        // tempered words of the current state
-    int pos;
-    bool wide;
-    void seed(uint32_t s) {
-        for (int i = 0; i < 624; i++) {
-            key[i] = s;
-            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
-        }
-        pos = 624;
-        wide = __builtin_cpu_supports("avx2");
-    }
-    void refill(uint32_t* out) { if (wide) refill_tempered_avx2(key, out); else refill_tempered_base(key, out); }
-    // the next n tempered outputs
-    void fill(uint32_t* out, size_t n) {
-        size_t done = 0;
-        while (done < n) {
-            if (pos == 624) {
-                if (n - done >= 624) { refill(out + done); done += 624; continue; }      // whole blocks go straight out
-                refill(block);
-                pos = 0;
-            }
-            size_t take = 624 - pos;
-            if (take > n - done) take = n - done;
-            std::memcpy(out + done, block + pos, take * 4);
-            pos += (int)take;
-            done += take;
-        }
+struct Cpu {
+    void (*next_state)(const uint32_t*, uint32_t*);
+    void (*temper)(uint32_t*, size_t);
+    Cpu() {
+        if (__builtin_cpu_supports("avx512f")) { next_state = next_state_512; temper = temper_512; }
+        else if (__builtin_cpu_supports("avx2")) { next_state = next_state_256; temper = temper_256; }
+        else { next_state = next_state_base; temper = temper_base; }
     }
 };
+const Cpu g_cpu;
+
+typedef std::array<uint32_t, NW> State;
+
+void seed_state(uint32_t s, State& key) {           // init_genrand
+    for (int i = 0; i < NW; i++) {
+        key[i] = s;
+        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
+    }
+}
 
 inline double to_double(uint32_t a, uint32_t b) {
     return ((a >> 5) * 67108864.0 + (b >> 6)) * (1.0 / 9007199254740992.0);      // a power of two: same bits as the division
 }
 
-constexpr size_t CHUNK = 8192;          // attempts a thread takes at a time
-constexpr size_t RING = 32;             // chunks of generator output in flight (4 MiB: stays in the last-level cache)
+constexpr size_t BLOCKS = 53;                       // state blocks a thread takes at a time ...
+constexpr size_t CHUNK = BLOCKS * NW / 4;           // ... = 8268 attempts of four outputs each
+constexpr size_t SLOT = BLOCKS * NW;                // words
+constexpr size_t RING = 32;                         // chunks in flight (4 MiB: stays in the last-level cache)
+static_assert(BLOCKS * NW % 4 == 0, "a chunk must hold whole attempts");
 
+struct Local {                                      // a follower's compaction buffers
+    std::vector<double> x1, x2, r2;
+    std::vector<uint32_t> att;
+    void reserve() { if (x1.size() < CHUNK) { x1.resize(CHUNK); x2.resize(CHUNK); r2.resize(CHUNK); att.resize(CHUNK); } }
+};
 struct Scratch {                        // survives between calls (a planner asks for the same amount at every step)
     std::mutex mu;
     std::vector<uint32_t> ring;
+    std::vector<Local> local;
 };
 Scratch g_scratch[64];                  // one per concurrent stream of mppi_numpy_normals_many; [0] for the single call
 
@@ -123,19 +137,20 @@ int usable_processors() {
 }
 
 // One stream: n values after np.random.seed(seed) into out, state_out as described at mppi_numpy_normals.
-// The calling thread runs the recurrence (sequential by nature) chunk by chunk into a ring; the other threads follow
-// behind it: a chunk's attempts are tested and compacted, its slot is handed back, its number of accepted pairs is
-// published, and as soon as the chunks before it have published theirs the chunk knows where its values go in `out`
-// and writes them there.
+// The calling thread runs the recurrence (sequential by nature) chunk by chunk into a ring, every state block made
+// from the one before it where it lies; the other threads follow behind it: a chunk is tempered in place, its
+// attempts are tested and compacted, its slot is handed back, its number of accepted pairs is published, and as soon
+// as the chunks before it have published theirs the chunk knows where its values go in `out` and writes them there.
 void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* state_out, Scratch& S) {
     std::lock_guard<std::mutex> lock(S.mu);
-    if (S.ring.size() < RING * CHUNK * 4) S.ring.resize(RING * CHUNK * 4);
+    if (S.ring.size() < RING * SLOT) S.ring.resize(RING * SLOT);
+    if (S.local.size() < (size_t)nthreads) S.local.resize(nthreads);
     uint32_t* const ring = S.ring.data();
-    MT19937 mt;
-    mt.seed(seed);
+    State key;                                        // the generator: state after the last block made
+    seed_state(seed, key);
     const size_t pairs = (n + 1) / 2;                 // accepted attempts needed (the last may give one value only)
     size_t have = 0;
-    MT19937 at_last = mt;                             // generator at the start of the chunk that holds the last pair
+    State at_last = key;                              // generator at the start of the chunk that holds the last pair
     size_t words_into_last = 0;                       // outputs numpy consumes from there on
     double cached = 0.0;
     while (have < pairs) {
@@ -144,7 +159,7 @@ void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* stat
         // simply never looked at (the generator object does not outlive the call: every call re-seeds).
         const size_t attempts = (size_t)((pairs - have) * 1.2733 + 8.0 * std::sqrt((double)(pairs - have))) + 64;
         const size_t nchunks = (attempts + CHUNK - 1) / CHUNK;
-        std::vector<MT19937> snapshot(nchunks);
+        std::vector<State> snapshot(nchunks);
         std::vector<std::atomic<int64_t>> offset(nchunks + 1);
         std::vector<std::atomic<uint8_t>> released(nchunks);
         for (auto& o : offset) o.store(-1, std::memory_order_relaxed);
@@ -157,16 +172,22 @@ void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* stat
         auto produce = [&](size_t c) {
             const size_t lo = c * CHUNK, hi = lo + CHUNK < attempts ? lo + CHUNK : attempts;
             if (c >= RING) wait_until([&] { return released[c - RING].load(std::memory_order_acquire) != 0; });
-            snapshot[c] = mt;
-            mt.fill(ring + (c % RING) * CHUNK * 4, 4 * (hi - lo));
+            snapshot[c] = key;
+            uint32_t* slot = ring + (c % RING) * SLOT;
+            const size_t blocks = (4 * (hi - lo) + NW - 1) / NW;
+            const uint32_t* prev = key.data();
+            for (size_t b = 0; b < blocks; b++) {
+                g_cpu.next_state(prev, slot + b * NW);
+                prev = slot + b * NW;
+            }
+            std::memcpy(key.data(), prev, NW * 4);
             made.store(c + 1, std::memory_order_release);
         };
-        struct Local { std::vector<double> x1, x2, r2; std::vector<uint32_t> att;
-                       Local() : x1(CHUNK), x2(CHUNK), r2(CHUNK), att(CHUNK) {} };
         auto consume = [&](size_t c, Local& L) {
             const size_t lo = c * CHUNK, hi = lo + CHUNK < attempts ? lo + CHUNK : attempts;
             wait_until([&] { return made.load(std::memory_order_acquire) > c; });
-            const uint32_t* raw = ring + (c % RING) * CHUNK * 4;
+            uint32_t* raw = ring + (c % RING) * SLOT;           // this thread's until it is released
+            g_cpu.temper(raw, 4 * (hi - lo));
             size_t k = 0;
             for (size_t a = 0; a < hi - lo; a++) {
                 const uint32_t* w = &raw[4 * a];
@@ -197,8 +218,9 @@ void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* stat
                 }
             }
         };
-        auto follow = [&] {
-            Local L;
+        auto follow = [&](int t) {
+            Local& L = S.local[t];
+            L.reserve();
             for (;;) {
                 const size_t c = next.fetch_add(1, std::memory_order_relaxed);
                 if (c >= nchunks) return;
@@ -208,13 +230,13 @@ void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* stat
 
         if (nthreads > 1 && nchunks >= 4) {
             std::vector<std::thread> pool;
-            for (int t = 1; t < nthreads; t++) pool.emplace_back(follow);
+            for (int t = 1; t < nthreads; t++) pool.emplace_back(follow, t);
             for (size_t c = 0; c < nchunks; c++) produce(c);
-            follow();
+            follow(0);
             for (auto& th : pool) th.join();
         } else {
-            Local L;
-            for (size_t c = 0; c < nchunks; c++) { produce(c); consume(c, L); }
+            S.local[0].reserve();
+            for (size_t c = 0; c < nchunks; c++) { produce(c); consume(c, S.local[0]); }
         }
         const size_t total = (size_t)offset[nchunks].load(std::memory_order_acquire);
         if (total >= pairs) {
@@ -226,11 +248,17 @@ void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* stat
         have = total;
     }
     if (state_out) {
-        // replay from the start of that chunk up to the last output numpy consumes
-        std::vector<uint32_t> sink(4 * CHUNK);
-        if (words_into_last) at_last.fill(sink.data(), words_into_last);
-        std::memcpy(state_out, at_last.key, 624 * 4);
-        state_out[624] = (uint32_t)at_last.pos;
+        // replay from the start of that chunk up to the block of the last output numpy consumes
+        const size_t regenerations = (words_into_last + NW - 1) / NW;
+        State other;
+        State* cur = &at_last;
+        State* nxt = &other;
+        for (size_t r = 0; r < regenerations; r++) {
+            g_cpu.next_state(cur->data(), nxt->data());
+            std::swap(cur, nxt);
+        }
+        std::memcpy(state_out, cur->data(), NW * 4);
+        state_out[624] = regenerations ? (uint32_t)(words_into_last - NW * (regenerations - 1)) : (uint32_t)NW;
         const bool has_gauss = (n % 2) == 1;
         state_out[625] = has_gauss ? 1u : 0u;
         const double g = has_gauss ? cached : 0.0;

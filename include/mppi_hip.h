@@ -109,7 +109,7 @@ typedef struct mppi_planner_cfg {
                            /*   Every per-planner array argument / result then holds the P */
                            /*   planners back to back; noise streams differ per planner.   */
     int32_t sweep_cap;     /* most sweeps of the constraint rows' active-set iteration per  */
-                           /*   physics substep; 0: the default, 12                        */
+                           /*   physics substep; 0: the default, 16                        */
     double kappa;
     double gamma;
     double sigma[MPPI_MAXV];   /* filter_coefs[0]                                          */

@@ -203,7 +203,7 @@ def test_status_reports_non_finite_returns(dm):
 
 
 def test_status_reports_a_capped_active_set_solve(dm, oracle_sim):
-    """With the default cap (12 sweeps) no solve of this workload is cut short; with a cap of 2 the substeps
+    """With the default cap (16 sweeps) no solve of this workload is cut short; with a cap of 2 the substeps
     that need a third sweep are, and MPPI_STATUS_SWEEP_CAP says so."""
     K, H = 2048, 32
     raw = ref_mppi.raw_normals(5, K, H, 7)

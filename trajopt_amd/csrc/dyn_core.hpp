@@ -66,7 +66,7 @@ MPPI_HD float rsqrt_t(float x) {
 MPPI_HD double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 MPPI_HD float rcp_t(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __frcp_rn(x);
+    return __builtin_amdgcn_rcpf(x);            // v_rcp_f32, 1 ulp (a correctly rounded quotient costs ten instructions)
 #else
     return 1.0f / x;
 #endif
@@ -286,7 +286,7 @@ template <class T, class MD> struct Step {
         T idle[NV + 1];
         // most sweeps the iteration may take (uniform over a wave); a solve that stops there with the set
         // still moving reports cap + 1 sweeps.  reset() keeps it.
-        int cap = 12;
+        int cap = 16;
         MPPI_HD void reset() { static_for<NV + 1>([&](auto Ic) { idle[Ic] = T(0); }); }
     };
 
@@ -338,50 +338,27 @@ template <class T, class MD> struct Step {
 
     static MPPI_HD void build_rows(const T (&q)[NQ], const Frames& fr, const T (&qd)[NV], Rows& r) {
         r.any = Mask<T>{};
-        // joint limits: at most one side can be violated; evaluated without branches.  A row deeper than
-        // the impedance ramp (solimp width) has the constant impedance dmax, so its weight is a constant of
-        // the model and its reference acceleration two multiply-adds; only when some lane of the wave has a
-        // row inside the ramp is the impedance polynomial evaluated (same values either way).
-        T pos[NV];
-        T shallowest = T(-1e30);      // the least negative violated distance: inside the ramp iff above -width
+        // joint limits: at most one side can be violated; evaluated without branches.  (A row deeper than the
+        // impedance ramp has constant weight, and a version that skipped the ramp polynomial unless some lane of
+        // the wave was inside the ramp existed: among 64 samples one almost always is, so the test and its
+        // branch only cost.)
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
-            r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1); pos[i] = T(0);
+            r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1);
             if constexpr (MD::limited[i] != 0) {
                 static_assert(!is_ball(i), "ball joints have no limit rows");
                 const T lo = q[MD::qadr[i]] - T(MD::range_lo[i]);
                 const T hi = T(MD::range_hi[i]) - q[MD::qadr[i]];
-                pos[i] = min_t(lo, hi);
+                const T pos = min_t(lo, hi);
                 r.sg[i] = sel(lo < hi, T(1), T(-1));
-                const Mask<T> on = pos[i] < T(0);
+                const Mask<T> on = pos < T(0);
                 r.any |= on;
-                shallowest = max_t(shallowest, sel(on, pos[i], T(-1e30)));
+                T D, ar;
+                row_constants(pos, r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
+                r.Dl[i] = sel(on, D, T(0));
+                r.arl[i] = sel(on, ar, T(0));
             }
         });
-        if (MPPI_UNLIKELY(wave_any(shallowest > T(-MD::solimp[2])))) {
-            static_for<NV>([&](auto Ic) {
-                constexpr int i = Ic;
-                if constexpr (MD::limited[i] != 0) {
-                    T D, ar;
-                    row_constants(pos[i], r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
-                    const Mask<T> on = pos[i] < T(0);
-                    r.Dl[i] = sel(on, D, T(0));
-                    r.arl[i] = sel(on, ar, T(0));
-                }
-            });
-        } else {
-            static_for<NV>([&](auto Ic) {
-                constexpr int i = Ic;
-                if constexpr (MD::limited[i] != 0) {
-                    const T imp = T(MD::solimp[1]);
-                    const T D = imp * rcp_t((T(1) - imp) * T(MD::dof_invweight[i]));      // folds to a constant
-                    const T ar = -T(MD::solref_b) * (r.sg[i] * qd[i]) - T(MD::solref_k) * imp * pos[i];
-                    const Mask<T> on = pos[i] < T(0);
-                    r.Dl[i] = sel(on, D, T(0));
-                    r.arl[i] = sel(on, ar, T(0));
-                }
-            });
-        }
         r.Dc = T(0); r.arc = T(0);
         static_for<NV>([&](auto Ic) { r.Jc[Ic] = T(0); });
         if constexpr (MD::contact_link >= 0) {
@@ -465,14 +442,16 @@ template <class T, class MD> struct Step {
             T sa[NV];                                  // sign of J times reference acceleration, per limit row
             static_for<NV>([&](auto Ic) { sa[Ic] = r.sg[Ic] * r.arl[Ic]; });
             T acc[NV], resl[NV], resc = T(0);
-            // residual signs decide the next active set; true if this lane's set changed
-            auto settle = [&]() -> Mask<T> {
+            // residual signs decide the next active set; true if this lane's set changed.  Grow: rows may join the
+            // set but not leave it (the late sweeps of a solve that keeps changing, see below).
+            auto settle = [&](auto Grow) -> Mask<T> {
+                constexpr bool GROW = decltype(Grow)::value;
                 Mask<T> changed{};
                 static_for<NV>([&](auto Ic) {
                     constexpr int i = Ic;
                     if constexpr (MD::limited[i] != 0) {
                         resl[i] = r.sg[i] * acc[i] - r.arl[i];
-                        const T nd = sel(resl[i] < T(0), r.Dl[i], T(0));
+                        const T nd = sel(resl[i] < T(0), r.Dl[i], GROW ? dg[i] : T(0));
                         changed |= (nd != dg[i]);
                         dg[i] = nd;
                     }
@@ -481,7 +460,7 @@ template <class T, class MD> struct Step {
                     T ja = T(0);
                     static_for<NV>([&](auto Ic) { ja += r.Jc[Ic] * acc[Ic]; });
                     resc = ja - r.arc;
-                    const T nd = sel(resc < T(0), r.Dc, T(0));
+                    const T nd = sel(resc < T(0), r.Dc, GROW ? dc : T(0));
                     changed |= (nd != dc);
                     dc = nd;
                 }
@@ -501,16 +480,32 @@ template <class T, class MD> struct Step {
                 right_hand_side();
                 // (a model without rows never gets here: its rows.any is false at compile time)
                 if constexpr (DUAL) dual_factor<WC, true>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.D, damped.inv);
-                Mask<T> changed = settle();
+                Mask<T> changed = settle(std::false_type{});
                 // a set carried over from the previous substep is usually confirmed by the first sweep
                 if (MPPI_UNLIKELY(wave_any(changed))) {
+                    // Rows join and leave the set freely for the first FREE sweeps, which settles all but a few
+                    // solves in a million.  The rest are rows whose residual is zero to rounding and whose sign
+                    // differs between the system with the row and the system without it: such a row would enter and
+                    // leave for ever.  From then on rows may only join (at most one sweep per row more); a row kept
+                    // that way carries a force of rounding size.
+                    constexpr int FREE = 6;
+                    const int free_end = act.cap < FREE ? act.cap : FREE;
                     do {
                         sweeps++;
                         right_hand_side();
                         chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
-                        changed = settle();
-                    } while (wave_any(changed) && sweeps < act.cap);
-                    if (MPPI_UNLIKELY(wave_any(changed))) sweeps = act.cap + 1;    // gave up: the forces belong to the last set tried
+                        changed = settle(std::false_type{});
+                    } while (wave_any(changed) && sweeps < free_end);
+                    if (MPPI_UNLIKELY(wave_any(changed))) {
+                        while (sweeps < act.cap) {
+                            sweeps++;
+                            right_hand_side();
+                            chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                            changed = settle(std::true_type{});
+                            if (!wave_any(changed)) break;
+                        }
+                        if (MPPI_UNLIKELY(wave_any(changed))) sweeps = act.cap + 1;    // gave up: the forces belong to the last set tried
+                    }
                 }
             };
             if (MPPI_UNLIKELY(wave_any(r.Dc > T(0)))) sweep_all(std::true_type{});

@@ -416,7 +416,7 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     p->HM = cfg->H * p->nv;
     p->P = cfg->P > 1 ? cfg->P : 1;
     p->cfg.P = p->P;
-    if (p->cfg.sweep_cap == 0) p->cfg.sweep_cap = 12;
+    if (p->cfg.sweep_cap == 0) p->cfg.sweep_cap = 16;
     p->esz = cfg->dtype == MPPI_F32 ? 4 : 8;
     p->cfg_gen = 1;
     p->prof_events = new std::vector<hipEvent_t>();

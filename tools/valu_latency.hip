@@ -35,6 +35,24 @@ __global__ void k(long long* out, float* sink, float seed) {
                         : "+v"(a), "+v"(d), "+v"(e), "+v"(f) : "v"(c), "v"(b));)
     t1 = clock64();
     if (threadIdx.x == 0) out[4] = t1 - t0;
+    // four independent rsq chains interleaved: the issue cost of a transcendental
+    a = fabsf(a) + 1.0f; d = fabsf(d) + 1.0f; e = fabsf(e) + 1.0f; f = fabsf(f) + 1.0f;
+    t0 = clock64();
+    REP256(asm volatile("v_rsq_f32 %0, %0\n v_rsq_f32 %1, %1\n v_rsq_f32 %2, %2\n v_rsq_f32 %3, %3" : "+v"(a), "+v"(d), "+v"(e), "+v"(f));)
+    t1 = clock64();
+    if (threadIdx.x == 0) out[9] = t1 - t0;
+    // one rsq and seven independent fmas: does the transcendental hold the issue port?
+    t0 = clock64();
+    REP256(asm volatile("v_rsq_f32 %0, %0\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %1, %1, %4, %5"
+                        : "+v"(a), "+v"(d), "+v"(e), "+v"(f) : "v"(c), "v"(b));)
+    t1 = clock64();
+    if (threadIdx.x == 0) out[10] = t1 - t0;
+    // eight independent fmas (same shape without the rsq)
+    t0 = clock64();
+    REP256(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n v_fma_f32 %1, %1, %4, %5"
+                        : "+v"(a), "+v"(d), "+v"(e), "+v"(f) : "v"(c), "v"(b));)
+    t1 = clock64();
+    if (threadIdx.x == 0) out[11] = t1 - t0;
     // v_cmp -> s_and -> v_cndmask round trip, dependent
     t0 = clock64();
     REP256(asm volatile("v_cmp_gt_f32 vcc, %0, %1\n s_and_b64 vcc, vcc, exec\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(a) : "v"(b), "v"(c) : "vcc");)
@@ -74,6 +92,9 @@ int main() {
         printf("  v_cmp->v_cndmask (group)         %.2f\n", h[6] / 256.0);
         printf("  dependent v_fma_f64 chain        %.2f\n", h[7] / 256.0);
         printf("  LDS write+barrier+read+barrier   %.2f\n", h[8] / 16.0);
+        printf("  4 interleaved rsq chains, per rsq %.2f\n", h[9] / 1024.0);
+        printf("  rsq + 7 independent fma (group)  %.2f\n", h[10] / 256.0);
+        printf("  8 independent fma (group)        %.2f\n", h[11] / 256.0);
         break;
     }
     return 0;

@@ -25,6 +25,11 @@
 #define MPPI_HD inline __attribute__((always_inline))
 #endif
 
+// host studies of the active-set iteration define this to see which row changed in which sweep
+#ifndef MPPI_SWEEP_TRACE
+#define MPPI_SWEEP_TRACE(sweep, row, changed) ((void)0)
+#endif
+
 namespace mppi {
 
 template <class F, int... Is>
@@ -452,6 +457,7 @@ template <class T, class MD> struct Step {
                     if constexpr (MD::limited[i] != 0) {
                         resl[i] = r.sg[i] * acc[i] - r.arl[i];
                         const T nd = sel(resl[i] < T(0), r.Dl[i], GROW ? dg[i] : T(0));
+                        MPPI_SWEEP_TRACE(sweeps, i, nd != dg[i]);
                         changed |= (nd != dg[i]);
                         dg[i] = nd;
                     }
@@ -461,6 +467,7 @@ template <class T, class MD> struct Step {
                     static_for<NV>([&](auto Ic) { ja += r.Jc[Ic] * acc[Ic]; });
                     resc = ja - r.arc;
                     const T nd = sel(resc < T(0), r.Dc, GROW ? dc : T(0));
+                    MPPI_SWEEP_TRACE(sweeps, NV, nd != dc);
                     changed |= (nd != dc);
                     dc = nd;
                 }

@@ -60,7 +60,7 @@ MPPI_HD void sincos_t(double x, double& s, double& c) {
 MPPI_HD float sqrt_t(float x) { return sqrtf(x); }
 MPPI_HD double sqrt_t(double x) { return sqrt(x); }
 // fp32 on the device uses the hardware reciprocal / reciprocal square root / sine / cosine
-// (about 1 ulp; the angle argument is bounded by the joint ranges); fp64 stays exact
+// (about 1 ulp; the angle argument is bounded by the joint ranges); fp64 keeps libm sine / cosine
 MPPI_HD float rsqrt_t(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __frsqrt_rn(x);
@@ -68,7 +68,19 @@ MPPI_HD float rsqrt_t(float x) {
     return 1.0f / std::sqrt(x);
 #endif
 }
-MPPI_HD double rsqrt_t(double x) { return 1.0 / sqrt(x); }
+// fp64 on the device: the hardware estimate (about 26 bits) and two Newton steps, a dozen instructions; sqrt() followed
+// by a division is four times that, most of it special cases that a positive pivot cannot be
+MPPI_HD double rsqrt_t(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
 MPPI_HD float rcp_t(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rcpf(x);            // v_rcp_f32, 1 ulp (a correctly rounded quotient costs ten instructions)
@@ -76,7 +88,16 @@ MPPI_HD float rcp_t(float x) {
     return 1.0f / x;
 #endif
 }
-MPPI_HD double rcp_t(double x) { return 1.0 / x; }
+MPPI_HD double rcp_t(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
 MPPI_HD float min_t(float a, float b) { return fminf(a, b); }
 MPPI_HD double min_t(double a, double b) { return fmin(a, b); }
 MPPI_HD float max_t(float a, float b) { return fmaxf(a, b); }

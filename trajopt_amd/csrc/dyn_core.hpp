@@ -57,10 +57,16 @@ MPPI_HD void sincos_t(double x, double& s, double& c) {
     s = std::sin(x); c = std::cos(x);
 #endif
 }
-MPPI_HD float sqrt_t(float x) { return sqrtf(x); }
 MPPI_HD double sqrt_t(double x) { return sqrt(x); }
-// fp32 on the device uses the hardware reciprocal / reciprocal square root / sine / cosine
+// fp32 on the device uses the hardware square root / reciprocal / reciprocal square root / sine / cosine
 // (about 1 ulp; the angle argument is bounded by the joint ranges); fp64 keeps libm sine / cosine
+MPPI_HD float sqrt_t(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 MPPI_HD float rsqrt_t(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __frsqrt_rn(x);

@@ -541,10 +541,15 @@ __device__ __forceinline__ double shfl_xor_d(double x, int m) { return __shfl_xo
 // ROWS = 1, 2 or 4 for few planners: as many blocks as there are CUs, no more (every block evaluates all K
 // weights, which is most of its time; a second block on a CU doubles the kernel's).  The last block of a
 // planner may own fewer rows.  Any block size that is a multiple of 64 up to 1024.
+//
+// Large K (weights != nullptr): the weights were evaluated once by update_weights_kernel -- [K] values, then Rmax and the
+// local arg-max -- and the blocks only stream them against their rows (otherwise every one of the blocks would evaluate
+// all K exponentials again).  Same values, same order of summation, same bits.
 template <class T, int NV, int ROWS>
 __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__ R, const T* __restrict__ eps, int K, double kappa,
                                                            int k_offset, int HM, int write_base, double* __restrict__ base,
-                                                           double* __restrict__ part, double* __restrict__ result) {
+                                                           double* __restrict__ part, double* __restrict__ result,
+                                                           const double* __restrict__ weights) {
     __shared__ double s_v[16][ROWS + 1];
     __shared__ int s_i[16];
     const int row0 = blockIdx.x * ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -553,6 +558,7 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     const int nr = (ROWS == NV || HM - row0 >= ROWS) ? ROWS : HM - row0;
     R += (size_t)blockIdx.y * K; eps += ((size_t)blockIdx.y * HM + row0) * K;
     base += (size_t)blockIdx.y * HM + row0; part += (size_t)blockIdx.y * (3 + HM); result += 2 * blockIdx.y;
+    if (weights) weights += (size_t)blockIdx.y * (K + 2);
     // Up to HOLD samples per thread stay in registers: the returns are read once, and the noise rows are
     // requested before the reduction that finds the maximum, so their latency is spent there.
     constexpr int HOLD = 4;
@@ -570,26 +576,30 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     }
     double bv = -DBL_MAX;
     int bi = INT_MAX;
-    if (held) {
-#pragma unroll
-        for (int e = 0; e < HOLD; e++) {
-            const int k = tid + e * nthreads;
-            if (k < K) argmax_combine(bv, bi, (double)rv[e], k);
-        }
+    if (weights) {
+        bv = weights[K]; bi = (int)weights[K + 1];
     } else {
-        for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
+        if (held) {
+    #pragma unroll
+            for (int e = 0; e < HOLD; e++) {
+                const int k = tid + e * nthreads;
+                if (k < K) argmax_combine(bv, bi, (double)rv[e], k);
+            }
+        } else {
+            for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
+        }
+    #pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double ov = shfl_xor_d(bv, m);
+            const int oi = __shfl_xor(bi, m, 64);
+            argmax_combine(bv, bi, ov, oi);
+        }
+        if (lane == 0) { s_v[wave][0] = bv; s_i[wave] = bi; }
+        __syncthreads();
+        bv = s_v[0][0]; bi = s_i[0];
+        for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
+        __syncthreads();
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = shfl_xor_d(bv, m);
-        const int oi = __shfl_xor(bi, m, 64);
-        argmax_combine(bv, bi, ov, oi);
-    }
-    if (lane == 0) { s_v[wave][0] = bv; s_i[wave] = bi; }
-    __syncthreads();
-    bv = s_v[0][0]; bi = s_i[0];
-    for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
-    __syncthreads();
     double acc[ROWS + 1];            // [ROWS]: sum of the weights
 #pragma unroll
     for (int j = 0; j <= ROWS; j++) acc[j] = 0.0;
@@ -605,8 +615,28 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
             }
         }
     } else {
-        for (int k = tid; k < K; k += nthreads) {
-            const double sk = exp(kappa * ((double)R[k] - bv));
+        // streaming: U samples' loads are in flight before the first is used; the sums run in the order of k
+        constexpr int U = 4;
+        int k = tid;
+        for (; k + (U - 1) * nthreads < K; k += U * nthreads) {
+            double sk[U];
+            T e[ROWS][U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                sk[u] = weights ? weights[k + u * nthreads] : (double)R[k + u * nthreads];
+#pragma unroll
+                for (int j = 0; j < ROWS; j++) e[j][u] = j < nr ? eps[(size_t)j * K + k + u * nthreads] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!weights) sk[u] = exp(kappa * (sk[u] - bv));
+#pragma unroll
+                for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk[u] * (double)e[j][u];
+                acc[ROWS] += sk[u];
+            }
+        }
+        for (; k < K; k += nthreads) {
+            const double sk = weights ? weights[k] : exp(kappa * ((double)R[k] - bv));
 #pragma unroll
             for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk * (double)eps[(size_t)j * K + k];
             acc[ROWS] += sk;
@@ -637,6 +667,33 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     }
 }
 
+// The weights of a planner with many samples, evaluated once: every block finds Rmax / the first arg-max itself (the
+// reduction of update_rows_kernel, so the same values), then the blocks share the K exponentials.  out: [K] weights,
+// Rmax, local arg-max, per planner.
+template <class T>
+__global__ void __launch_bounds__(1024) update_weights_kernel(const T* __restrict__ R, int K, double kappa, double* __restrict__ out) {
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    R += (size_t)blockIdx.y * K; out += (size_t)blockIdx.y * (K + 2);
+    double bv = -DBL_MAX;
+    int bi = INT_MAX;
+    for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = shfl_xor_d(bv, m);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    __syncthreads();
+    bv = s_v[0]; bi = s_i[0];
+    for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w], s_i[w]);
+    const int per = (K + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < K ? lo + per : K;
+    for (int k = lo + tid; k < hi; k += nthreads) out[k] = exp(kappa * ((double)R[k] - bv));
+    if (blockIdx.x == 0 && tid == 0) { out[K] = bv; out[K + 1] = (double)bi; }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-model dispatch
 // ------------------------------------------------------------------------------------------
@@ -663,7 +720,7 @@ struct ModelOps {
     hipError_t (*advance_noise)(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                 const double* mean, double* log, int log_cap, int* log_count, int K, int k_offset, uint64_t seed,
                                 const int* next_step, const FilterCoefs& fc, void* eps, hipStream_t);
-    hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, int write_base, double* base,
+    hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, int write_base, double* weights, double* base,
                               double* part, double* result, hipStream_t);
 };
 
@@ -792,9 +849,12 @@ static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int d
         hipLaunchKernelGGL((critic_kernel<double, MD::NV>), grid, block, 0, s, (const double*)fobs, K, dim, w, g_last, (double*)R);
     return hipGetLastError();
 }
+// more samples than a block holds in registers, few planners: the weights are worth evaluating once
+inline bool update_wants_weights(int K, int H, int P) { return K > 4096 && (long)H * P < 1024; }
+// weights: scratch of P * (K + 2) doubles for update_weights_kernel, or null (every block evaluates the weights itself)
 template <class MD>
 static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset,
-                                     int write_base, double* base, double* part, double* result, hipStream_t s) {
+                                     int write_base, double* weights, double* base, double* part, double* result, hipStream_t s) {
     constexpr int NV = MD::NV;
     const int HM = H * NV;
     const dim3 block(K > 1024 ? 1024 : 256);
@@ -804,12 +864,19 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
         const dim3 grid((HM + (ROWS_) - 1) / (ROWS_), P);                                                                       \
         if (dtype == MPPI_F32)                                                                                                  \
             hipLaunchKernelGGL((update_rows_kernel<float, NV, ROWS_>), grid, block, 0, s, (const float*)R, (const float*)eps,  \
-                               K, kappa, k_offset, HM, write_base, base, part, result);                                        \
+                               K, kappa, k_offset, HM, write_base, base, part, result, w);                                     \
         else                                                                                                                    \
             hipLaunchKernelGGL((update_rows_kernel<double, NV, ROWS_>), grid, block, 0, s, (const double*)R, (const double*)eps, \
-                               K, kappa, k_offset, HM, write_base, base, part, result);                                        \
+                               K, kappa, k_offset, HM, write_base, base, part, result, w);                                     \
     } while (0)
     const int cus = 256;
+    const double* w = nullptr;
+    if (weights && update_wants_weights(K, H, P)) {
+        const dim3 wgrid(K >= 262144 ? 64 : 32, P);
+        if (dtype == MPPI_F32) hipLaunchKernelGGL((update_weights_kernel<float>), wgrid, dim3(1024), 0, s, (const float*)R, K, kappa, weights);
+        else hipLaunchKernelGGL((update_weights_kernel<double>), wgrid, dim3(1024), 0, s, (const double*)R, K, kappa, weights);
+        w = weights;
+    }
     if ((long)H * P >= 1024) MPPI_LAUNCH_UPDATE(NV);                        // many planners: one block per step
     else if ((long)HM * P <= cus) MPPI_LAUNCH_UPDATE(1);
     else if ((long)((HM + 1) / 2) * P <= cus) MPPI_LAUNCH_UPDATE(2);

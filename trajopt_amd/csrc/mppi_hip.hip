@@ -283,6 +283,7 @@ struct mppi_planner {
     void* d_eps;           // T [H][M][K]
     double* d_raw;         // staging for host uploads [K][H][M]
     double* h_stage;       // page-locked host buffer of the same size, made on request
+    double* d_weights;     // [P][K + 2] the update's weights, Rmax, arg-max: large K only (update_wants_weights)
     double* d_ref;
     int ref_cap;
     void* d_R;             // T [K]
@@ -344,6 +345,7 @@ static int planner_allocate(mppi_planner* p) {
     HIP_OK(hipMemset(p->d_part, 0, (3 * P + HM) * 8));
     HIP_OK(hipMalloc(&p->d_result, 2 * 8 * P));
     HIP_OK(hipMemset(p->d_result, 0, 2 * 8 * P));
+    if (update_wants_weights(cfg->K, cfg->H, (int)P)) HIP_OK(hipMalloc(&p->d_weights, P * ((size_t)cfg->K + 2) * 8));
     HIP_OK(hipMalloc(&p->d_status, 16));
     HIP_OK(hipMemset(p->d_status, 0, 16));
     HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (p->nq + 2 * p->nv + 7) * 8));
@@ -450,6 +452,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     }
     if (p->d_gathered) (void)hipFree(p->d_gathered);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
+    if (p->d_weights) (void)hipFree(p->d_weights);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R,
                     p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
     for (void* b : bufs)
@@ -682,13 +685,13 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
 
 static int launch_partials(mppi_planner* p, hipStream_t s) {
     HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 0,
-                                      p->d_base, p->d_part, p->d_result, s));
+                                      p->d_weights, p->d_base, p->d_part, p->d_result, s));
     return 0;
 }
 
 static int launch_update_fused(mppi_planner* p, hipStream_t s) {
     HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 1,
-                                      p->d_base, p->d_part, p->d_result, s));
+                                      p->d_weights, p->d_base, p->d_part, p->d_result, s));
     return 0;
 }
 

@@ -388,7 +388,7 @@ template <class T, class MD> struct Step {
                 T D, ar;
                 row_constants(pos, r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
                 r.Dl[i] = sel(on, D, T(0));
-                r.arl[i] = sel(on, ar, T(0));
+                r.arl[i] = ar;          // (meaningless without the row, and never used then: a row of weight 0 stays out)
             }
         });
         r.Dc = T(0); r.arc = T(0);
@@ -847,12 +847,14 @@ template <class T, class MD> struct Step {
     static MPPI_HD void row_constants(T x, T vel, T invweight, T& D, T& aref) {
         const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]), mid = T(MD::solimp[3]);
         static_assert(MD::solimp[4] == 2.0, "impedance power other than 2 is not compiled in");
-        const T u = abs_t(x) * T(1.0 / MD::solimp[2]);
+        // beyond the ramp (u >= 1) the impedance is dmax: with u held at 1 the upper branch gives y = 1 and
+        // d0 + (dmax - d0), which is dmax exactly (the difference of two numbers this close is exact)
+        const T u = min_t(abs_t(x) * T(1.0 / MD::solimp[2]), T(1));
         const T w = T(1) - u;
         const T ylo = u * u * T(1.0 / MD::solimp[3]);
         const T yhi = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3]));
         const T y = sel(u <= mid, ylo, yhi);
-        const T imp = sel(u < T(1), d0 + y * (dmax - d0), dmax);
+        const T imp = d0 + y * (dmax - d0);
         aref = -T(MD::solref_b) * vel - T(MD::solref_k) * imp * x;
         D = imp * rcp_t((T(1) - imp) * invweight);
     }

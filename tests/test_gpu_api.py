@@ -313,6 +313,32 @@ def test_worker_streams_leave_the_global_numpy_stream_alone_with_several_workers
     assert np.array_equal(a[:4], b[:4]) and np.array_equal(a[4:8], all_worker_normals(9, 4, 1, 6, 7))
 
 
+def test_host_noise_drawn_ahead_is_invisible():
+    """`train_step` draws the host noise of the next planning step while the device works on the current one.  A caller
+    cannot tell: the same act_sequence and the same process-global numpy generator after every step as with the
+    draws made on demand, also when the seed is changed between two steps (what was drawn ahead is then dropped)."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    runs = []
+    for ahead in (True, False):
+        e = get_environment('reacher_7dof')
+        e.reset_model(seed=2, goal=(0.05, 0.0, 0.05))
+        ag = MPPI(e, H=8, paths_per_cpu=24, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=11)
+        ag.draw_ahead = ahead
+        np.random.seed(1)
+        trace = []
+        for step in range(7):
+            if step == 3:
+                ag.seed = 500                   # the stream drawn ahead for step 3 is no longer the one asked for
+            if step == 5:
+                ag.kappa = 10.0                 # a parameter that leaves the stream alone
+            ag.train_step(niter=2)
+            trace.append((ag.act_sequence.copy(), np.random.get_state()[1].copy(), np.random.get_state()[2], np.random.uniform()))
+        runs.append(trace)
+    for (a1, k1, p1, u1), (a2, k2, p2, u2) in zip(*runs):
+        assert np.array_equal(a1, a2) and np.array_equal(k1, k2) and p1 == p2 and u1 == u2
+
+
 def test_pickled_agent_resolves_through_the_trajopt_names(tmp_path):
     """An agent pickled under the reference's module names loads back onto this implementation."""
     import pickletools

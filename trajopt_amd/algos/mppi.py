@@ -17,8 +17,8 @@ Two keyword arguments are additions with behaviour-preserving defaults:
 import numpy as np
 
 from ..device import DeviceModel, DevicePlanner, update_from_returns
-from ..utils import (ReplayBuffer, Tuple, all_worker_normals, gather_paths_parallel, rollout_objective,  # noqa: F401
-                     score_trajectory)
+from ..utils import (ReplayBuffer, Tuple, _set_numpy_state, all_worker_normals, gather_paths_parallel,  # noqa: F401
+                     rollout_objective, score_trajectory)
 from .trajopt_base import Trajectory
 
 _KERNEL_ENVS = {'reacher_7dof': 'reacher_7dof', 'continual_reacher_7dof': 'reacher_7dof'}
@@ -74,12 +74,15 @@ class MPPI(Trajectory):
         self.dtype = dtype
         self._planner = None
         self._planner_key = None
+        self._ahead = None              # (key, numpy state record) of host noise drawn for the next planning step
+        self.draw_ahead = True
 
     # ---- pickling: device handles are dropped and rebuilt on demand -------------------------
     def __getstate__(self):
         d = dict(self.__dict__)
         d.pop('_planner', None)
         d.pop('_planner_key', None)
+        d.pop('_ahead', None)
         return d
 
     def __setstate__(self, d):
@@ -88,6 +91,8 @@ class MPPI(Trajectory):
         self.__dict__.setdefault('dtype', 'f32')
         self._planner = None
         self._planner_key = None
+        self._ahead = None
+        self.__dict__.setdefault('draw_ahead', True)
 
     # ---- device planner -----------------------------------------------------------------
     def _device_planner(self):
@@ -98,6 +103,7 @@ class MPPI(Trajectory):
         if self._planner is None or key != self._planner_key:
             if self._planner is not None:
                 self._planner.close()
+            self._ahead = None
             model = DeviceModel.get(_KERNEL_ENVS[self.env.env_name])
             self._planner = DevicePlanner(model, self.paths_per_cpu * self.num_cpu, self.H, kappa=self.kappa,
                                           gamma=self.gamma, sigma=sig, betas=(b0, b1, b2), mean=self.mean,
@@ -169,9 +175,26 @@ class MPPI(Trajectory):
         p.set_critic(critic_dim, critic_weights)         # a no-op while dim and weights stay what they were
         if self.noise == 'philox':
             p.generate_noise(seed)
+            p.iterate(niter)
         else:
-            p.upload_noise(all_worker_normals(seed, self.paths_per_cpu, self.num_cpu, H, self.m, out=p.host_staging()))
-        p.iterate(niter)
+            # The host stream of planning step t + 1 depends on nothing but its seed, so it is drawn while the device
+            # works on step t (the staging buffer is free again once the upload has returned).  What was drawn ahead
+            # is used only if the next call asks for exactly that stream from the same planner; the process-global
+            # numpy generator is moved when the draws are consumed, as if they had been made then.
+            buf = p.host_staging()
+            want = (id(p), seed, self.paths_per_cpu, self.num_cpu, H, self.m)
+            if self._ahead is not None and self._ahead[0] == want:
+                state = self._ahead[1]
+            else:
+                _, state = all_worker_normals(seed, self.paths_per_cpu, self.num_cpu, H, self.m, out=buf, defer_state=True)
+            self._ahead = None
+            if state is not None:
+                _set_numpy_state(state)
+            p.upload_noise(buf)
+            p.iterate(niter)
+            if self.draw_ahead and 0 <= seed + 1 < 2 ** 32:
+                _, state = all_worker_normals(seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m, out=buf, defer_state=True)
+                self._ahead = ((id(p), seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m), state)
         self.act_sequence = p.act_sequence()
 
     def _attach_critic_rewards(self, paths, critic, dim):

@@ -217,7 +217,12 @@ def _host_threads():
     return _HOST_THREADS
 
 
-def worker_normals(base_seed, n_paths, H, m, in_process=True, out=None):
+def _set_numpy_state(state):
+    """Put the process-global legacy generator where the library's 628-word state record says."""
+    np.random.set_state(("MT19937", state[:624], int(state[624]), int(state[625]), float(state[626:628].view(np.float64)[0])))
+
+
+def worker_normals(base_seed, n_paths, H, m, in_process=True, out=None, defer_state=False):
     """Raw N(0,1) draws of one reference worker: seed once, then n_paths blocks of (H, m) in
     order (`generate_paths`, trajopt/utils.py:135-139) -- numpy's legacy stream, produced in bulk by the
     library's generator (same bits as `np.random.seed(base_seed)` + `np.random.normal(size=(H, m))` calls).
@@ -225,7 +230,9 @@ def worker_normals(base_seed, n_paths, H, m, in_process=True, out=None):
     trajopt/utils.py:171-172), which leaves the process-global numpy generator re-seeded and advanced past the
     draws: the global state is set to exactly that.  Pool workers re-seed only their own copy, so with several
     workers the caller's generator is left alone.
-    out: a C-contiguous float64 array of shape (n_paths, H, m) to fill instead of a new one."""
+    out: a C-contiguous float64 array of shape (n_paths, H, m) to fill instead of a new one.
+    defer_state: leave the global generator alone and return (draws, state record) instead; the caller applies the
+    record with `_set_numpy_state` when the draws are consumed (draws made ahead of time)."""
     from . import _lib as L
     seed = int(base_seed)
     if not 0 <= seed < 2 ** 32:
@@ -237,12 +244,14 @@ def worker_normals(base_seed, n_paths, H, m, in_process=True, out=None):
     rc = L.lib().mppi_numpy_normals(seed, out.size, L.ptr(out), _host_threads(), L.ptr(state))
     if rc != 0:
         raise RuntimeError("mppi_numpy_normals failed")
+    if defer_state:
+        return out, state
     if in_process:
-        np.random.set_state(("MT19937", state[:624], int(state[624]), int(state[625]), float(state[626:628].view(np.float64)[0])))
+        _set_numpy_state(state)
     return out
 
 
-def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m, out=None):
+def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m, out=None, defer_state=False):
     """(K, H, m) draws in global sample order k = worker * paths_per_cpu + j, worker i seeded
     with base_seed + i * paths_per_cpu (trajopt/utils.py:151-152: overlapping streams).
     out: a (K, H, m) float64 array to fill (a planner's page-locked staging buffer) instead of a new one."""
@@ -250,7 +259,7 @@ def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m, out=None):
         out = np.empty((paths_per_cpu * num_cpu, H, m))
     assert out.shape == (paths_per_cpu * num_cpu, H, m) and out.dtype == np.float64 and out.flags.c_contiguous
     if num_cpu == 1:
-        return worker_normals(base_seed, paths_per_cpu, H, m, in_process=True, out=out)
+        return worker_normals(base_seed, paths_per_cpu, H, m, in_process=True, out=out, defer_state=defer_state)
     from . import _lib as L
     seeds = [int(base_seed) + i * paths_per_cpu for i in range(num_cpu)]
     if not all(0 <= s < 2 ** 32 for s in seeds):
@@ -258,7 +267,7 @@ def all_worker_normals(base_seed, paths_per_cpu, num_cpu, H, m, out=None):
     seeds = np.array(seeds, dtype=np.uint32)
     if L.lib().mppi_numpy_normals_many(L.ptr(seeds), num_cpu, paths_per_cpu * H * m, L.ptr(out), _host_threads()) != 0:
         raise RuntimeError("mppi_numpy_normals_many failed")
-    return out
+    return (out, None) if defer_state else out
 
 
 def generate_paths(env_name, start_state, N, base_act, filter_coefs, base_seed, goal, reward_type, reference, alpha):

@@ -155,14 +155,11 @@ __device__ __forceinline__ bool nonfinite(double x) {
     return (hi & 0x7ff00000u) == 0x7ff00000u;
 }
 
-#ifndef MPPI_ROLLOUT_ATTR
-#define MPPI_ROLLOUT_ATTR
-#endif
 // LEAN: the planning configuration (dense reward, noise-relative samples, nothing dumped, no reference, no
 // critic) with those choices fixed at compile time: a lone wave pays about ten vector instructions' time for
 // every taken branch, and the general kernel spends eight per env step on options that are off.
 template <class T, class MD, bool LEAN>
-__global__ void __launch_bounds__(64) MPPI_ROLLOUT_ATTR
+__global__ void __launch_bounds__(64)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
                const double* __restrict__ ref, int K, int H, int reward_type_, double gamma, int explicit_act_,
                T* __restrict__ R, T* __restrict__ obs_, T* __restrict__ rew_, int* __restrict__ status,

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mppi_hip.h"
@@ -965,17 +966,34 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) try {
         if (rc) return rc;
         HIP_OK(hipMemcpy(base.data(), p->d_base, P * HM * 8, hipMemcpyDeviceToHost));
         double* o = (double*)dst;
-        for (size_t b = 0; b < P; b++)
-            for (size_t k = 0; k < K; k++)
+        const bool explicit_act = p->explicit_act != 0, f32 = p->cfg.dtype == MPPI_F32;
+        // device layout [step, dimension][sample] -> (sample, step, dimension), in tiles of 64 samples so that reads run
+        // along the samples and the 64 output rows being filled stay in cache; tiles are spread over a few threads
+        constexpr size_t TILE = 64;
+        const size_t tiles = (K + TILE - 1) / TILE, jobs = P * tiles;
+        auto run = [&](size_t lo, size_t hi) {
+            for (size_t job = lo; job < hi; job++) {
+                const size_t b = job / tiles, k0 = (job % tiles) * TILE, k1 = k0 + TILE < K ? k0 + TILE : K;
                 for (size_t hm = 0; hm < HM; hm++) {
-                    // same arithmetic as the kernel: the sum is formed in the rollout dtype
-                    const double bb = base[b * HM + hm], x = e[(b * HM + hm) * K + k];
-                    double a;
-                    if (p->explicit_act) a = x;
-                    else if (p->cfg.dtype == MPPI_F32) a = (double)((float)bb + (float)x);
-                    else a = bb + x;
-                    o[(b * K + k) * HM + hm] = a;
+                    const double bb = base[b * HM + hm];
+                    const double* x = &e[(b * HM + hm) * K];
+                    for (size_t k = k0; k < k1; k++) {
+                        // same arithmetic as the kernel: the sum is formed in the rollout dtype
+                        double a;
+                        if (explicit_act) a = x[k];
+                        else if (f32) a = (double)((float)bb + (float)x[k]);
+                        else a = bb + x[k];
+                        o[(b * K + k) * HM + hm] = a;
+                    }
                 }
+            }
+        };
+        const size_t nthreads = jobs >= 32 ? 8 : 1, per = (jobs + nthreads - 1) / nthreads;
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++)
+            if (t * per < jobs) pool.emplace_back(run, t * per, (t + 1) * per < jobs ? (t + 1) * per : jobs);
+        run(0, per < jobs ? per : jobs);
+        for (auto& th : pool) th.join();
         return 0;
     }
     case MPPI_READ_NEXT_OBS:

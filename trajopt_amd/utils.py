@@ -160,6 +160,31 @@ class _StatesView(Sequence):
                     timestep=self._t0 + t)
 
 
+class _RowsView(Sequence):
+    """`next_observations` of one path (trajopt/utils.py:91,99: a list of H observation vectors) over the rows of the
+    block read back from the device: rows come out as arrays on access, `np.asarray(view)` is the block itself."""
+
+    def __init__(self, block):
+        self._block = block
+
+    def __len__(self):
+        return self._block.shape[0]
+
+    def __getitem__(self, t):
+        if isinstance(t, slice):
+            return list(self._block[t])
+        return self._block[t]
+
+    def __iter__(self):
+        return iter(self._block)
+
+    def __array__(self, dtype=None, copy=None):
+        return self._block if dtype is None else self._block.astype(dtype)
+
+    def __eq__(self, other):
+        return len(other) == len(self) and all(np.array_equal(a, b) for a, b in zip(self, other))
+
+
 def _paths_from_device(p, start_state, act, env_name):
     """Build the reference's list-of-dict `paths` (trajopt/utils.py:94-99) from device buffers.
     Arrays are per-sample views of the K-sample blocks read back from the device."""
@@ -183,7 +208,7 @@ def _paths_from_device(p, start_state, act, env_name):
                           rewards=rew[k],
                           env_infos=dict(state=dict(qp=ok[:, :nv], qv=ok[:, nv:2 * nv], target_pos=tp, timestep=timesteps)),
                           states=_StatesView(ok, target, t0, nv),
-                          next_observations=list(nobs[k])))
+                          next_observations=_RowsView(nobs[k])))
     return paths
 
 

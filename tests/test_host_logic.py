@@ -124,3 +124,22 @@ def test_critic_module_reproduces_the_reference_module_on_its_trained_weights():
         assert np.abs(v - g["v%d" % dim]).max() < 1e-4 * np.abs(g["v%d" % dim]).max()
         # the slicing helper the example scripts use gives the same inputs
         assert np.array_equal(np.stack([c.compress_state(o, dim) for o in g["obs"]]).astype(np.float32), x.numpy())
+
+
+def test_rows_view_behaves_like_the_list_of_observation_vectors():
+    """`next_observations` of a path is a list of H vectors in the reference (trajopt/utils.py:91,99); the view over the
+    device block answers the same questions without making H arrays per path up front."""
+    import pickle
+    from trajopt_amd.utils import _RowsView
+    block = np.arange(12.0).reshape(4, 3)
+    v = _RowsView(block)
+    as_list = list(block)
+    assert len(v) == 4 and np.array_equal(v[-1], as_list[-1]) and np.array_equal(v[1], as_list[1])
+    assert all(np.array_equal(a, b) for a, b in zip(v, as_list)) and v == as_list
+    assert isinstance(v[1:3], list) and np.array_equal(np.array(v[1:3]), block[1:3])
+    assert np.asarray(v) is block and np.array(v).shape == (4, 3) and np.asarray(v, dtype=np.float32).dtype == np.float32
+    assert np.array_equal(np.asarray(pickle.loads(pickle.dumps(v))), block)
+    import torch
+    assert torch.tensor(np.asarray(v), dtype=torch.float32).shape == (4, 3)
+    with pytest.raises(IndexError):
+        v[4]

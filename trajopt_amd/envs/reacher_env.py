@@ -12,13 +12,30 @@ from ..device import DeviceModel
 
 
 class _Data:
-    """`sim.data` look-alike: qpos, qvel and the two site positions the examples read."""
+    """`sim.data` look-alike: qpos, qvel and the two site positions the examples read.
+
+    `site_xpos` after `sim.forward()` is the end-effector position of the current qpos, which costs a kernel launch
+    and a read-back; it is computed when somebody looks at it, not when forward() is called (a `set_env_state`
+    followed by `step`, as in `MPPI.advance_time`, never looks)."""
 
     def __init__(self, nv):
         self.qpos = np.zeros(nv)
         self.qvel = np.zeros(nv)
         self.ctrl = np.zeros(nv)
-        self.site_xpos = np.zeros((2, 3))
+        self._site_xpos = np.zeros((2, 3))
+        self._refresh = None                # callable that brings _site_xpos up to date, or None when it is
+
+    @property
+    def site_xpos(self):
+        if self._refresh is not None:
+            refresh, self._refresh = self._refresh, None
+            refresh()
+        return self._site_xpos
+
+    @site_xpos.setter
+    def site_xpos(self, value):
+        self._refresh = None
+        self._site_xpos = np.asarray(value, dtype=np.float64)
 
 
 class _Model:
@@ -100,8 +117,13 @@ class Reacher7DOFEnv:
 
     # ---- simulation -----------------------------------------------------------------
     def _forward(self):
-        self.data.site_xpos[self.hand_sid] = self._dev.forward_hand(self.data.qpos)
-        self.data.site_xpos[self.target_sid] = self.model.site_pos[self.target_sid]
+        # the positions belong to the configuration at the time of the call, whenever they are looked at
+        qpos, target = self.data.qpos.copy(), self.model.site_pos[self.target_sid].copy()
+        self.data._refresh = lambda: self._forward_now(qpos, target)
+
+    def _forward_now(self, qpos, target):
+        self.data._site_xpos[self.hand_sid] = self._dev.forward_hand(qpos)
+        self.data._site_xpos[self.target_sid] = target
 
     def _seed(self, seed=None):
         self.np_random = np.random.RandomState(seed)
@@ -119,8 +141,9 @@ class Reacher7DOFEnv:
         self.data.ctrl[:] = a
         self.data.qpos[:] = q2
         self.data.qvel[:] = v2
-        self.data.site_xpos[self.hand_sid] = obs[-6:-3]        # position before the last substep's integration
-        self.data.site_xpos[self.target_sid] = self.model.site_pos[self.target_sid]
+        self.data._refresh = None                              # the step leaves its own site positions
+        self.data._site_xpos[self.hand_sid] = obs[-6:-3]       # position before the last substep's integration
+        self.data._site_xpos[self.target_sid] = self.model.site_pos[self.target_sid]
         return r
 
     def _step(self, a):

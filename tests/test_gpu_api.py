@@ -36,6 +36,27 @@ def test_env_duck_type_and_transitions(transitions, oracle_sim):
     assert e2.env_name == 'reacher_7dof' and e2.env_timestep == 1
 
 
+def test_site_positions_belong_to_the_forward_call(oracle_sim):
+    """`sim.forward()` fixes `site_xpos` for the configuration it was called with (trajopt/envs/mujoco_env.py:120-128);
+    here the kernel launch behind it is put off until somebody reads the positions, and must still answer for that
+    configuration, not for whatever qpos holds by then."""
+    from trajopt.envs.utils import get_environment
+    e = get_environment('reacher_7dof')
+    q1, q2 = np.linspace(-0.4, 0.3, 7), np.linspace(0.2, -0.5, 7)
+    e.set_state(q1, np.zeros(7))
+    e.data.qpos[:] = q2                                   # no forward() after this
+    assert np.allclose(e.data.site_xpos[e.hand_sid], oracle_sim.fk_hand(q1), atol=1e-13)
+    e.sim.forward()
+    assert np.allclose(e.data.site_xpos[e.hand_sid], oracle_sim.fk_hand(q2), atol=1e-13)
+    # a step leaves its own (one substep old) hand position; a forward() asked for before it is forgotten
+    e.set_state(q1, np.zeros(7))
+    ob, _, _, _ = e.step(np.zeros(7))
+    assert np.array_equal(e.data.site_xpos[e.hand_sid], ob[14:17])
+    # assigning the array is allowed, as with the simulator's own buffer
+    e.data.site_xpos[e.target_sid] = (0.1, 0.2, 0.3)
+    assert np.array_equal(e._get_obs()[17:20], (0.1, 0.2, 0.3))
+
+
 def test_reward_types(oracle_sim):
     from trajopt.envs.utils import get_environment
     rs = np.random.RandomState(0)

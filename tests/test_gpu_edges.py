@@ -248,3 +248,25 @@ def test_page_locked_staging_uploads_like_any_host_array(dm):
     assert np.array_equal(a.actions(), b.actions()) and np.array_equal(a.returns(), b.returns())
     assert np.abs(a.actions()).max() > 0
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_log_ring_wraps_and_reads_back_in_order(dm):
+    """The real-env log keeps the last 4096 steps; a read that spans the end of the ring comes back oldest first, the
+    same rows a read before the wrap returned."""
+    from trajopt_amd.device import DevicePlanner
+    p = DevicePlanner(dm, 64, 2, kappa=25.0, sigma=np.ones(7), betas=(0.25, 0.8, 0.0), default_act="mean")
+    p.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, 0.0, 0.1]), 0)
+    p.set_base_actions(np.zeros((2, 7)))
+    p.plan(5, 1, 4090)
+    before = p.read_log(max_rows=50)
+    assert before["total"] == 4090 and before["qpos"].shape == (50, 7)
+    p.plan(5, 1, 16)                                  # steps 4090 .. 4105: the ring's end lies inside the last 50
+    after = p.read_log(max_rows=50)
+    assert after["total"] == 4106 and after["qpos"].shape == (50, 7)
+    for k in ("qpos", "qvel", "hand", "reward", "action"):
+        assert np.array_equal(after[k][:34], before[k][16:]), k
+    full = p.read_log()
+    assert full["qpos"].shape == (4096, 7) and np.array_equal(full["qpos"][-50:], after["qpos"])
+    assert p.status() & 1 == 0
+    p.close()

@@ -627,10 +627,13 @@ int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_ro
     const double* ring = p->d_log + (size_t)planner * MPPI_LOG_CAP * row;
     int n = count < MPPI_LOG_CAP ? count : MPPI_LOG_CAP;
     if (n > max_rows) n = max_rows;
-    // the n most recent rows, oldest first
-    for (int i = 0; i < n; i++) {
-        const int src = (count - n + i) % MPPI_LOG_CAP;
-        HIP_OK(hipMemcpy(rows + (size_t)i * row, ring + (size_t)src * row, (size_t)row * 8, hipMemcpyDeviceToHost));
+    // the n most recent rows, oldest first: one copy, or two when the run wraps around the end of the ring
+    if (n > 0) {
+        const int first = (count - n) % MPPI_LOG_CAP;
+        const int head = n < MPPI_LOG_CAP - first ? n : MPPI_LOG_CAP - first;
+        HIP_OK(hipMemcpy(rows, ring + (size_t)first * row, (size_t)head * row * 8, hipMemcpyDeviceToHost));
+        if (head < n)
+            HIP_OK(hipMemcpy(rows + (size_t)head * row, ring, (size_t)(n - head) * row * 8, hipMemcpyDeviceToHost));
     }
     *n_rows = n;
     if (total) *total = count;

@@ -207,6 +207,12 @@ class Reacher7DOFEnv:
     def reset(self):
         return self.reset_model()
 
+    def _reset(self):
+        """gym's hook (trajopt/envs/mujoco_env.py:114-118): simulator reset, forward, model reset."""
+        self.sim.reset()
+        self.sim.forward()
+        return self.reset_model()
+
     # ---- state dicts ---------------------------------------------------------------------
     def get_env_state(self):
         return dict(qp=self.data.qpos.copy(), qv=self.data.qvel.copy(),
@@ -224,6 +230,12 @@ class Reacher7DOFEnv:
     # ---- headless stand-ins for the viewer hooks --------------------------------------------
     def mj_viewer_setup(self):
         self.viewer = None
+
+    def viewer_setup(self):
+        pass
+
+    def _get_viewer(self, mode=None):
+        return None
 
     def mj_render(self):
         pass

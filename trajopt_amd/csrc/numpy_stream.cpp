@@ -83,7 +83,6 @@ struct Cpu {
     void (*next_state)(const uint32_t*, uint32_t*);
     void (*temper)(uint32_t*, size_t);
     Cpu() {
-        __builtin_cpu_init();           // this object is built during static initialisation
         if (__builtin_cpu_supports("avx512f")) { next_state = next_state_512; temper = temper_512; }
         else if (__builtin_cpu_supports("avx2")) { next_state = next_state_256; temper = temper_256; }
         else { next_state = next_state_base; temper = temper_base; }

@@ -368,6 +368,33 @@ def test_device_resident_advance_matches_host_driven_loop(dev_model, oracle_sim)
     assert np.abs(q2 - log["qpos"][-1]).max() < 1e-10 and abs(r2 - log["reward"][-1]) < 1e-10
 
 
+@pytest.mark.parametrize("P,K", [(1, 4097), (1, 5000), (3, 4608), (2, 9001)])
+def test_update_with_many_samples_per_planner(dev_model, P, K):
+    """Beyond 4096 samples a planner's weights are evaluated once by their own kernel and the row blocks stream them:
+    ragged sample counts, several planners per handle, statistics of a shard, all against the numpy update."""
+    H = 6
+    rs = np.random.RandomState(K)
+    b = _planner(dev_model, K, H, "f64", planners=P)
+    q0 = rs.uniform(-0.3, 0.3, (P, 7)) if P > 1 else rs.uniform(-0.3, 0.3, 7)
+    v0 = np.zeros_like(q0)
+    tgt = rs.uniform(-0.1, 0.1, (P, 3)) if P > 1 else rs.uniform(-0.1, 0.1, 3)
+    base = rs.randn(*((P, H, 7) if P > 1 else (H, 7))) * 0.1
+    b.set_start_state(q0, v0, tgt, 0 if P == 1 else np.zeros(P, dtype=np.int32))
+    b.set_base_actions(base)
+    b.generate_noise(11)
+    b.rollout()
+    R, act = b.returns(), b.actions()
+    b.iterate(1)
+    seq, am = b.act_sequence(), b.argmax()
+    for pl in range(P):
+        Rp, ap = (R[pl], act[pl]) if P > 1 else (R, act)
+        want = ref_mppi.update(ap, Rp, 25.0)
+        got = seq[pl] if P > 1 else seq
+        assert np.abs(got - want).max() < 1e-12, (pl, np.abs(got - want).max())
+        assert (am[pl] if P > 1 else am) == int(np.argmax(Rp))
+    b.close()
+
+
 def test_batched_planners_equal_independent_planners(dev_model, oracle_sim):
     """One handle with P planners (own start state, base actions, noise) gives, planner by planner,
     what P separate handles give; and its rollouts are the oracle's."""

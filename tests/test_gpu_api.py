@@ -334,7 +334,8 @@ def test_worker_streams_leave_the_global_numpy_stream_alone_with_several_workers
     assert np.array_equal(a[:4], b[:4]) and np.array_equal(a[4:8], all_worker_normals(9, 4, 1, 6, 7))
 
 
-def test_host_noise_drawn_ahead_is_invisible():
+@pytest.mark.parametrize("num_cpu", [1, 3])
+def test_host_noise_drawn_ahead_is_invisible(num_cpu):
     """`train_step` draws the host noise of the next planning step while the device works on the current one.  A caller
     cannot tell: the same act_sequence and the same process-global numpy generator after every step as with the
     draws made on demand, also when the seed is changed between two steps (what was drawn ahead is then dropped)."""
@@ -344,7 +345,7 @@ def test_host_noise_drawn_ahead_is_invisible():
     for ahead in (True, False):
         e = get_environment('reacher_7dof')
         e.reset_model(seed=2, goal=(0.05, 0.0, 0.05))
-        ag = MPPI(e, H=8, paths_per_cpu=24, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=11)
+        ag = MPPI(e, H=8, paths_per_cpu=24, num_cpu=num_cpu, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=11)
         ag.draw_ahead = ahead
         np.random.seed(1)
         trace = []

@@ -42,8 +42,8 @@ __global__ void __launch_bounds__(64) c_build_rows(const float* in, float* out) 
     static_for<NV>([&](auto I) { q[I] = IN(3 * NV + I); fr.cs(I) = IN(I); fr.sn(I) = IN(NV + I); qd[I] = IN(2 * NV + I); });
     typename S::Rows r;
     S::build_rows(q, fr, qd, r);
-    static_for<NV>([&](auto I) { OUT(I) = r.Dl[I]; OUT(NV + I) = r.arl[I]; OUT(2 * NV + I) = r.sg[I]; OUT(3 * NV + I) = r.Jc[I]; });
-    OUT(4 * NV) = r.Dc + r.arc + (r.any ? 1.f : 0.f);
+    static_for<NV>([&](auto I) { OUT(I) = r.Dl[I]; OUT(NV + I) = r.sal[I]; OUT(2 * NV + I) = r.xs[I]; OUT(3 * NV + I) = r.Jc[I]; });
+    OUT(4 * NV) = r.Dc + r.arc;
 }
 __global__ void __launch_bounds__(64) c_hand_site(const float* in, float* out) {
     float q[NV];

@@ -304,11 +304,15 @@ template <class T, class MD> struct Step {
         else return xp;
     }
 
-    // soft constraint rows of one substep: joint limits (one possible row per joint) and the contact
+    // soft constraint rows of one substep: joint limits (one possible row per joint) and the contact.
+    // A limit row is described in joint coordinates, without the sign of its Jacobian: xs = q - clamp(q, lo, hi) is
+    // the signed violation (negative below the lower limit, positive above the upper one, zero inside the range),
+    // sal = J * aref the reference acceleration of the joint itself.  With t = qacc - sal the row's residual
+    // J qacc - aref is J t and J = -sign(xs): the row is active (residual < 0) iff t * xs > 0, and its force on the
+    // joint is -D t.
     struct Rows {
-        T Dl[NV], arl[NV], sg[NV];   // limit rows: weight (0 = no row), reference acceleration, sign of J
+        T Dl[NV], sal[NV], xs[NV];   // limit rows: weight (0 = no row), reference acceleration of the joint, signed violation
         T Jc[NV], Dc, arc;           // contact row: Jacobian, weight (0 = no row), reference acceleration
-        Mask<T> any;
     };
     // Which rows ended the previous substep inactive ([i]: limit row of joint i, [NV]: contact row): the
     // weight such a row was not given, > 0 only for a row that existed and was inactive.  Carried through a
@@ -369,26 +373,22 @@ template <class T, class MD> struct Step {
     }
 
     static MPPI_HD void build_rows(const T (&q)[NQ], const Frames& fr, const T (&qd)[NV], Rows& r) {
-        r.any = Mask<T>{};
         // joint limits: at most one side can be violated; evaluated without branches.  (A row deeper than the
         // impedance ramp has constant weight, and a version that skipped the ramp polynomial unless some lane of
         // the wave was inside the ramp existed: among 64 samples one almost always is, so the test and its
         // branch only cost.)
         static_for<NV>([&](auto Ic) {
             constexpr int i = Ic;
-            r.Dl[i] = T(0); r.arl[i] = T(0); r.sg[i] = T(1);
+            r.Dl[i] = T(0); r.sal[i] = T(0); r.xs[i] = T(0);
             if constexpr (MD::limited[i] != 0) {
                 static_assert(!is_ball(i), "ball joints have no limit rows");
-                const T lo = q[MD::qadr[i]] - T(MD::range_lo[i]);
-                const T hi = T(MD::range_hi[i]) - q[MD::qadr[i]];
-                const T pos = min_t(lo, hi);
-                r.sg[i] = sel(lo < hi, T(1), T(-1));
-                const Mask<T> on = pos < T(0);
-                r.any |= on;
-                T D, ar;
-                row_constants(pos, r.sg[i] * qd[i], T(MD::dof_invweight[i]), D, ar);
-                r.Dl[i] = sel(on, D, T(0));
-                r.arl[i] = ar;          // (meaningless without the row, and never used then: a row of weight 0 stays out)
+                const T qi = q[MD::qadr[i]];
+                const T xs = qi - min_t(max_t(qi, T(MD::range_lo[i])), T(MD::range_hi[i]));
+                T D, sa;
+                row_constants(xs, qd[i], T(MD::dof_invweight[i]), D, sa);
+                r.Dl[i] = sel(xs != T(0), D, T(0));
+                r.sal[i] = sa;          // (meaningless without the row, and never used then: a row of weight 0 stays out)
+                r.xs[i] = xs;
             }
         });
         r.Dc = T(0); r.arc = T(0);
@@ -422,7 +422,6 @@ template <class T, class MD> struct Step {
                 row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), Dc, arc);
                 r.Dc = sel(near, Dc, T(0));
                 r.arc = sel(near, arc, T(0));
-                r.any |= near;
             }
         }
     }
@@ -462,61 +461,69 @@ template <class T, class MD> struct Step {
     //              inside the first sweep, entry by entry next to the constraint system's own factor
     //              (one packed instruction serves both).
     // The loop is uniform over the wave: lanes whose set has settled repeat the same solve (same result)
-    // until every lane has settled, so the only cross-lane operation is one vote per sweep.
+    // until every lane has settled, so the only cross-lane operation is one vote per sweep.  A model with rows
+    // always runs the first sweep, also in the rare substep in which no lane of the wave has a row (all weights
+    // zero then: the sweep is the unconstrained solve): a test for that case is a branch on every substep.
     static MPPI_HD void constraint_forces(const T (&M)[NV][NV], const T (&fs)[NV], const Rows& r, Active& act,
                                           T (&fc)[NV], int& sweeps_out, DampedFactor& damped) {
-        static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
-        int sweeps = 0;
-        if (MPPI_LIKELY(wave_any(r.any))) {
+        if constexpr (!has_rows()) {
+            static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
+            factor_damped(M, damped);
+            sweeps_out = 0;
+        } else {
+            int sweeps = 0;
             // active weight of every row: its D while active, 0 while inactive or absent
             T dg[NV], dc = sel(act.idle[NV] > T(0), T(0), r.Dc);
             static_for<NV>([&](auto Ic) { dg[Ic] = sel(act.idle[Ic] > T(0), T(0), r.Dl[Ic]); });
-            T sa[NV];                                  // sign of J times reference acceleration, per limit row
-            static_for<NV>([&](auto Ic) { sa[Ic] = r.sg[Ic] * r.arl[Ic]; });
-            T acc[NV], resl[NV], resc = T(0);
-            // residual signs decide the next active set; true if this lane's set changed.  Grow: rows may join the
-            // set but not leave it (the late sweeps of a solve that keeps changing, see below).
-            auto settle = [&](auto Grow) -> Mask<T> {
-                constexpr bool GROW = decltype(Grow)::value;
-                Mask<T> changed{};
-                static_for<NV>([&](auto Ic) {
-                    constexpr int i = Ic;
-                    if constexpr (MD::limited[i] != 0) {
-                        resl[i] = r.sg[i] * acc[i] - r.arl[i];
-                        const T nd = sel(resl[i] < T(0), r.Dl[i], GROW ? dg[i] : T(0));
-                        MPPI_SWEEP_TRACE(sweeps, i, nd != dg[i]);
-                        changed |= (nd != dg[i]);
-                        dg[i] = nd;
-                    }
-                });
-                if constexpr (MD::contact_link >= 0) {
-                    T ja = T(0);
-                    static_for<NV>([&](auto Ic) { ja += r.Jc[Ic] * acc[Ic]; });
-                    resc = ja - r.arc;
-                    const T nd = sel(resc < T(0), r.Dc, GROW ? dc : T(0));
-                    MPPI_SWEEP_TRACE(sweeps, NV, nd != dc);
-                    changed |= (nd != dc);
-                    dc = nd;
-                }
-                return changed;
-            };
+            T acc[NV], tl[NV], resc = T(0);
+            static_for<NV>([&](auto Ic) { tl[Ic] = T(0); });
             T hb[NV];
             static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::INTEGRATOR == 0 ? MD::H * MD::damping[Ic] : 0.0); });
             // the sweeps exist twice, with and without the contact row, chosen once per substep: a taken
             // branch costs a lone wave about as much as a dozen vector instructions
             auto sweep_all = [&](auto Wc) {
                 constexpr bool WC = decltype(Wc)::value;
+                // residual signs decide the next active set; true if this lane's set changed.  Grow: rows may join the
+                // set but not leave it (the late sweeps of a solve that keeps changing, see below).
+                auto settle = [&](auto Grow) -> Mask<T> {
+                    constexpr bool GROW = decltype(Grow)::value;
+                    Mask<T> changed{};
+                    static_for<NV>([&](auto Ic) {
+                        constexpr int i = Ic;
+                        if constexpr (MD::limited[i] != 0) {
+                            tl[i] = acc[i] - r.sal[i];
+                            const T nd = sel(tl[i] * r.xs[i] > T(0), r.Dl[i], GROW ? dg[i] : T(0));
+                            MPPI_SWEEP_TRACE(sweeps, i, nd != dg[i]);
+                            changed |= (nd != dg[i]);
+                            dg[i] = nd;
+                        }
+                    });
+                    if constexpr (WC) {
+                        T ja = T(0);
+                        static_for<NV>([&](auto Ic) { ja += r.Jc[Ic] * acc[Ic]; });
+                        resc = ja - r.arc;
+                        const T nd = sel(resc < T(0), r.Dc, GROW ? dc : T(0));
+                        MPPI_SWEEP_TRACE(sweeps, NV, nd != dc);
+                        changed |= (nd != dc);
+                        dc = nd;
+                    }
+                    return changed;
+                };
                 auto right_hand_side = [&]() {
-                    static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + dg[Ic] * sa[Ic]; });
+                    static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + dg[Ic] * r.sal[Ic]; });
                     if constexpr (WC) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
                 };
                 sweeps = 1;
                 right_hand_side();
-                // (a model without rows never gets here: its rows.any is false at compile time)
-                if constexpr (DUAL) dual_factor<WC, true>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.D, damped.inv);
+                dual_factor<WC, true>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.D, damped.inv);
                 Mask<T> changed = settle(std::false_type{});
-                // a set carried over from the previous substep is usually confirmed by the first sweep
-                if (MPPI_UNLIKELY(wave_any(changed))) {
+                // Among the 64 samples of a wave one nearly always moves a row (a limit row released by a new torque,
+                // a joint arriving at its limit), so the second sweep is laid out as the fall-through path.
+                if (MPPI_LIKELY(wave_any(changed))) {
+                    sweeps = 2;
+                    right_hand_side();
+                    chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                    changed = settle(std::false_type{});
                     // Rows join and leave the set freely for the first FREE sweeps, which settles all but a few
                     // solves in a million.  The rest are rows whose residual is zero to rounding and whose sign
                     // differs between the system with the row and the system without it: such a row would enter and
@@ -524,42 +531,48 @@ template <class T, class MD> struct Step {
                     // that way carries a force of rounding size.
                     constexpr int FREE = 6;
                     const int free_end = act.cap < FREE ? act.cap : FREE;
-                    do {
-                        sweeps++;
-                        right_hand_side();
-                        chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
-                        changed = settle(std::false_type{});
-                    } while (wave_any(changed) && sweeps < free_end);
                     if (MPPI_UNLIKELY(wave_any(changed))) {
-                        while (sweeps < act.cap) {
+                        while (sweeps < free_end) {
                             sweeps++;
                             right_hand_side();
                             chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
-                            changed = settle(std::true_type{});
+                            changed = settle(std::false_type{});
                             if (!wave_any(changed)) break;
                         }
-                        if (MPPI_UNLIKELY(wave_any(changed))) sweeps = act.cap + 1;    // gave up: the forces belong to the last set tried
+                        if (MPPI_UNLIKELY(wave_any(changed))) {
+                            while (sweeps < act.cap) {
+                                sweeps++;
+                                right_hand_side();
+                                chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                                changed = settle(std::true_type{});
+                                if (!wave_any(changed)) break;
+                            }
+                            if (MPPI_UNLIKELY(wave_any(changed))) sweeps = act.cap + 1;    // gave up: the forces belong to the last set tried
+                        }
                     }
                 }
+                // force of every active row on its joint
+                static_for<NV>([&](auto Ic) {
+                    constexpr int i = Ic;
+                    if constexpr (MD::limited[i] != 0) fc[i] = -dg[i] * tl[i];
+                    else fc[i] = T(0);
+                });
+                if constexpr (WC) {
+                    const T f = -dc * resc;
+                    static_for<NV>([&](auto Ic) { fc[Ic] += r.Jc[Ic] * f; });
+                }
             };
-            if (MPPI_UNLIKELY(wave_any(r.Dc > T(0)))) sweep_all(std::true_type{});
-            else sweep_all(std::false_type{});
-            static_for<NV>([&](auto Ic) {
-                constexpr int i = Ic;
-                if constexpr (MD::limited[i] != 0) fc[i] = -r.sg[i] * dg[i] * resl[i];
-            });
             if constexpr (MD::contact_link >= 0) {
-                const T f = -dc * resc;
-                static_for<NV>([&](auto Ic) { fc[Ic] += r.Jc[Ic] * f; });
+                if (MPPI_UNLIKELY(wave_any(r.Dc > T(0)))) sweep_all(std::true_type{});
+                else sweep_all(std::false_type{});
+            } else {
+                sweep_all(std::false_type{});
             }
             // the weight withheld from every row: positive for the inactive ones, zero for active and absent rows
             static_for<NV>([&](auto Ic) { act.idle[Ic] = r.Dl[Ic] - dg[Ic]; });
             act.idle[NV] = r.Dc - dc;
-        } else {
-            act.reset();
-            factor_damped(M, damped);
+            sweeps_out = sweeps;
         }
-        sweeps_out = sweeps;
     }
 
     // qpos advanced from q0 by h along `vel`: hinge and slide coordinates move linearly, a ball joint's quaternion
@@ -843,20 +856,37 @@ template <class T, class MD> struct Step {
         }
     }
 
-    // impedance, stiffness/damping reference and regulariser of one constraint row
-    static MPPI_HD void row_constants(T x, T vel, T invweight, T& D, T& aref) {
-        const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]), mid = T(MD::solimp[3]);
+    // Impedance, regulariser and reference acceleration of one constraint row.
+    //   xs  : signed violation (a limit row: q - clamp(q, lo, hi); the contact row: distance - margin, negative)
+    //   vel : velocity of the joint (limit row) or J qvel (contact row)
+    //   D   : 1 / R, R = (1 - d) / d * invweight
+    //   sa  : reference acceleration -b vel - k d xs, in the coordinates vel and xs are given in
+    // The impedance d rises from d0 to dmax over the ramp u = |xs| / width in [0, 1]: y(u) = u^2 / mid below mid,
+    // 1 - (1 - u)^2 / (1 - mid) above.  For mid = 1/2 the two branches are one expression,
+    // y = 1/2 + 2 z (1 - |z|) with z = u - 1/2, which needs no comparison; 1 - d is formed from the same product
+    // (not by subtracting d from 1: d is within 5 % of 1 and the difference would lose four bits).
+    static MPPI_HD void row_constants(T xs, T vel, T invweight, T& D, T& sa) {
         static_assert(MD::solimp[4] == 2.0, "impedance power other than 2 is not compiled in");
-        // beyond the ramp (u >= 1) the impedance is dmax: with u held at 1 the upper branch gives y = 1 and
-        // d0 + (dmax - d0), which is dmax exactly (the difference of two numbers this close is exact)
-        const T u = min_t(abs_t(x) * T(1.0 / MD::solimp[2]), T(1));
-        const T w = T(1) - u;
-        const T ylo = u * u * T(1.0 / MD::solimp[3]);
-        const T yhi = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3]));
-        const T y = sel(u <= mid, ylo, yhi);
-        const T imp = d0 + y * (dmax - d0);
-        aref = -T(MD::solref_b) * vel - T(MD::solref_k) * imp * x;
-        D = imp * rcp_t((T(1) - imp) * invweight);
+        const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]);
+        T imp, omi;
+        if constexpr (MD::solimp[3] == 0.5) {
+            const T z = min_t(abs_t(xs) * T(1.0 / MD::solimp[2]) - T(0.5), T(0.5));
+            const T p = z * (T(1) - abs_t(z));
+            constexpr double half_rise = 0.5 * (MD::solimp[1] - MD::solimp[0]);
+            imp = T(MD::solimp[0] + half_rise) + T(4.0 * half_rise) * p;
+            omi = T(1.0 - MD::solimp[0] - half_rise) - T(4.0 * half_rise) * p;
+        } else {
+            const T mid = T(MD::solimp[3]);
+            const T u = min_t(abs_t(xs) * T(1.0 / MD::solimp[2]), T(1));
+            const T w = T(1) - u;
+            const T ylo = u * u * T(1.0 / MD::solimp[3]);
+            const T yhi = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3]));
+            const T y = sel(u <= mid, ylo, yhi);
+            imp = d0 + y * (dmax - d0);
+            omi = T(1) - imp;
+        }
+        sa = -T(MD::solref_b) * vel - T(MD::solref_k) * (imp * xs);
+        D = imp * rcp_t(omi * invweight);
     }
 
     // ---- dense solver -----------------------------------------------------------------------------

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64) c_build_rows(const float* in, float* out) 
     static_for<NV>([&](auto I) { q[I] = IN(3 * NV + I); fr.cs(I) = IN(I); fr.sn(I) = IN(NV + I); qd[I] = IN(2 * NV + I); });
     typename S::Rows r;
     S::build_rows(q, fr, qd, r);
-    static_for<NV>([&](auto I) { OUT(I) = r.Dl[I]; OUT(NV + I) = r.sal[I]; OUT(2 * NV + I) = r.xs[I]; OUT(3 * NV + I) = r.Jc[I]; });
+    static_for<NV>([&](auto I) { OUT(I) = r.Dl[I / 2][I % 2]; OUT(NV + I) = r.sal[I / 2][I % 2]; OUT(2 * NV + I) = r.xs[I / 2][I % 2]; OUT(3 * NV + I) = r.Jc[I]; });
     OUT(4 * NV) = r.Dc + r.arc;
 }
 __global__ void __launch_bounds__(64) c_hand_site(const float* in, float* out) {
@@ -84,5 +84,5 @@ __global__ void __launch_bounds__(64) c_substep(const float* in, float* out) {
     typename S::Active am; am.reset(); int sw;
     S::substep(q, v, a, in[0] > 0, o, am, sw);
     static_for<NV>([&](auto I) { OUT(I) = q[I]; OUT(NV + I) = v[I]; });
-    OUT(1000) = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am.idle[0] + am.idle[NV];
+    OUT(1000) = o.hand.v[0] + o.hand.v[1] + o.hand.v[2] + am.idle[0][0] + am.idle_contact;
 }

@@ -110,6 +110,8 @@ MPPI_HD float max_t(float a, float b) { return fmaxf(a, b); }
 MPPI_HD double max_t(double a, double b) { return fmax(a, b); }
 MPPI_HD float abs_t(float x) { return fabsf(x); }
 MPPI_HD double abs_t(double x) { return fabs(x); }
+MPPI_HD float clamp_t(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+MPPI_HD double clamp_t(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 // Conditions on a sample are consumed with sel() (a select, never a branch): the per-sample code stays
 // one straight instruction stream whatever the lanes of a wave decide.
@@ -132,13 +134,6 @@ MPPI_HD bool wave_any(bool x) {
 #define MPPI_LIKELY(x) __builtin_expect(!!(x), 1)
 #define MPPI_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
-// keeps the instruction scheduler from moving work across this point (device only)
-MPPI_HD void sched_fence() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
 constexpr int sym_idx(int i, int j) { return i == j ? i : i + j + 2; }   // xx yy zz xy xz yz
 
 template <class T> struct Vec3 { T v[3]; };
@@ -152,6 +147,13 @@ template <> struct PairOf<float> { typedef float type __attribute__((vector_size
 template <> struct PairOf<double> { typedef double type __attribute__((vector_size(16))); };
 template <class T> using Pair = typename PairOf<T>::type;
 template <class T> MPPI_HD Pair<T> make_pair_of(T a, T b) { Pair<T> p = {a, b}; return p; }
+// the operations that have no packed instruction, half by half
+MPPI_HD Pair<float> abs_t(Pair<float> x) { return make_pair_of(abs_t(x[0]), abs_t(x[1])); }
+MPPI_HD Pair<double> abs_t(Pair<double> x) { return make_pair_of(abs_t(x[0]), abs_t(x[1])); }
+MPPI_HD Pair<float> min_t(Pair<float> x, float b) { return make_pair_of(min_t(x[0], b), min_t(x[1], b)); }
+MPPI_HD Pair<double> min_t(Pair<double> x, double b) { return make_pair_of(min_t(x[0], b), min_t(x[1], b)); }
+MPPI_HD Pair<float> rcp_t(Pair<float> x) { return make_pair_of(rcp_t(x[0]), rcp_t(x[1])); }
+MPPI_HD Pair<double> rcp_t(Pair<double> x) { return make_pair_of(rcp_t(x[0]), rcp_t(x[1])); }
 // a pair of which only half H is ever looked at (the other half costs no instruction on the device)
 template <int H, class T> MPPI_HD Pair<T> half_pair(T a) {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(MPPI_UNDEF_HALVES)      // (the macro: host builds under MemorySanitizer)
@@ -310,20 +312,27 @@ template <class T, class MD> struct Step {
     // sal = J * aref the reference acceleration of the joint itself.  With t = qacc - sal the row's residual
     // J qacc - aref is J t and J = -sign(xs): the row is active (residual < 0) iff t * xs > 0, and its force on the
     // joint is -D t.
+    // The per-joint quantities are held as pairs of neighbouring joints {2p, 2p+1}: the elementwise arithmetic of the
+    // solve (right-hand sides, residuals, forces) is one packed instruction per pair.
+    static constexpr int NP = (NV + 1) / 2;
     struct Rows {
-        T Dl[NV], sal[NV], xs[NV];   // limit rows: weight (0 = no row), reference acceleration of the joint, signed violation
-        T Jc[NV], Dc, arc;           // contact row: Jacobian, weight (0 = no row), reference acceleration
+        Pair<T> Dl[NP], sal[NP], xs[NP];   // limit rows: weight (0 = no row), reference acceleration of the joint, signed violation
+        T Jc[NV], Dc, arc;                 // contact row: Jacobian, weight (0 = no row), reference acceleration
     };
-    // Which rows ended the previous substep inactive ([i]: limit row of joint i, [NV]: contact row): the
+    // Which rows ended the previous substep inactive: the
     // weight such a row was not given, > 0 only for a row that existed and was inactive.  Carried through a
     // rollout as the starting guess of the active-set solve; every other row, the ones that did not exist
     // included, starts active when it next appears.
     struct Active {
-        T idle[NV + 1];
+        Pair<T> idle[NP];       // limit rows, joints {2p, 2p+1}
+        T idle_contact;
         // most sweeps the iteration may take (uniform over a wave); a solve that stops there with the set
         // still moving reports cap + 1 sweeps.  reset() keeps it.
         int cap = 16;
-        MPPI_HD void reset() { static_for<NV + 1>([&](auto Ic) { idle[Ic] = T(0); }); }
+        MPPI_HD void reset() {
+            static_for<NP>([&](auto Pc) { idle[Pc] = make_pair_of(T(0), T(0)); });
+            idle_contact = T(0);
+        }
     };
 
     static MPPI_HD void frames(const T (&q)[NQ], Frames& fr) {
@@ -377,18 +386,41 @@ template <class T, class MD> struct Step {
         // impedance ramp has constant weight, and a version that skipped the ramp polynomial unless some lane of
         // the wave was inside the ramp existed: among 64 samples one almost always is, so the test and its
         // branch only cost.)
-        static_for<NV>([&](auto Ic) {
+        // Neighbouring joints go through the row arithmetic as a pair (one packed instruction for both wherever
+        // the instruction set has one).
+        auto clamped = [&](auto Ic) -> T {
             constexpr int i = Ic;
-            r.Dl[i] = T(0); r.sal[i] = T(0); r.xs[i] = T(0);
-            if constexpr (MD::limited[i] != 0) {
-                static_assert(!is_ball(i), "ball joints have no limit rows");
-                const T qi = q[MD::qadr[i]];
-                const T xs = qi - min_t(max_t(qi, T(MD::range_lo[i])), T(MD::range_hi[i]));
-                T D, sa;
-                row_constants(xs, qd[i], T(MD::dof_invweight[i]), D, sa);
-                r.Dl[i] = sel(xs != T(0), D, T(0));
-                r.sal[i] = sa;          // (meaningless without the row, and never used then: a row of weight 0 stays out)
-                r.xs[i] = xs;
+            return clamp_t(q[MD::qadr[i]], T(MD::range_lo[i]), T(MD::range_hi[i]));
+        };
+        static_for<NP>([&](auto Pc) {
+            constexpr int i0 = 2 * Pc, i1 = (2 * Pc + 1 < NV) ? 2 * Pc + 1 : i0;
+            static_assert(MD::limited[i0] == 0 || !is_ball(i0), "ball joints have no limit rows");
+            static_assert(MD::limited[i1] == 0 || !is_ball(i1), "ball joints have no limit rows");
+            if constexpr (RAMP_ONE_EXPRESSION && i1 != i0 && MD::limited[i0] != 0 && MD::limited[i1] != 0) {
+                // (positions and velocities stay single values: pairing them here would tie their registers down
+                // for the whole step)
+                const Pair<T> xs = make_pair_of(q[MD::qadr[i0]] - clamped(std::integral_constant<int, i0>{}),
+                                                q[MD::qadr[i1]] - clamped(std::integral_constant<int, i1>{}));
+                Pair<T> D, sa;
+                row_from_ramp(make_pair_of(ramp_product(xs[0]), ramp_product(xs[1])), xs,
+                              make_pair_of(T(MD::solref_b) * qd[i0], T(MD::solref_b) * qd[i1]),
+                              make_pair_of(T(MD::dof_invweight[i0]), T(MD::dof_invweight[i1])), D, sa);
+                r.Dl[Pc] = make_pair_of(sel(xs[0] != T(0), D[0], T(0)), sel(xs[1] != T(0), D[1], T(0)));
+                r.sal[Pc] = sa;      // (meaningless without the row, and never used then: a row of weight 0 stays out)
+                r.xs[Pc] = xs;
+            } else {
+                r.Dl[Pc] = make_pair_of(T(0), T(0)); r.sal[Pc] = r.Dl[Pc]; r.xs[Pc] = r.Dl[Pc];
+                static_for<(i1 != i0) ? 2 : 1>([&](auto Hc) {
+                    constexpr int h = Hc, i = i0 + h;
+                    if constexpr (MD::limited[i] != 0) {
+                        const T xs = q[MD::qadr[i]] - clamped(std::integral_constant<int, i>{});
+                        T D, sa;
+                        row_constants(xs, T(MD::solref_b) * qd[i], T(MD::dof_invweight[i]), D, sa);
+                        r.Dl[Pc][h] = sel(xs != T(0), D, T(0));
+                        r.sal[Pc][h] = sa;
+                        r.xs[Pc][h] = xs;
+                    }
+                });
             }
         });
         r.Dc = T(0); r.arc = T(0);
@@ -419,7 +451,7 @@ template <class T, class MD> struct Step {
                     }
                 });
                 T Dc, arc;
-                row_constants(dist - T(MD::contact_margin), vel, T(MD::contact_invweight), Dc, arc);
+                row_constants(dist - T(MD::contact_margin), T(MD::solref_b) * vel, T(MD::contact_invweight), Dc, arc);
                 r.Dc = sel(near, Dc, T(0));
                 r.arc = sel(near, arc, T(0));
             }
@@ -429,7 +461,6 @@ template <class T, class MD> struct Step {
     // semi-implicit Euler with implicit joint damping: (M + h B) a = fs + fc, v += h a, q += h v.
     // The factor of M + h B does not depend on the forces and may be computed ahead of them.
     // a lower-triangular matrix held as pairs of rows (see the dense solver below)
-    static constexpr int NP = (NV + 1) / 2;
     struct PackedSystem { Pair<T> col[NV][NP]; };      // col[j][p] = rows {2p, 2p+1} of column j, 2p+1 >= j
     // two lower-triangular matrices held entry by entry side by side (see the dense solver below)
     struct DualSystem { Pair<T> a[NV][NV]; };
@@ -453,7 +484,7 @@ template <class T, class MD> struct Step {
         } else chol_factor<false>(M, hb, T(0), hb, f.P, f.inv);
     }
 
-    // exact active-set solve of the soft constraint rows: fc = J^T f with f >= 0 on the active rows.
+    // exact active-set solve of the soft constraint rows: ftot = fs + J^T f with f >= 0 on the active rows.
     //   act      : active rows carried from the previous substep; reset() at the start of a rollout.  The
     //              iteration converges to the same unique solution from any start; starting from the
     //              previous set usually needs one sweep.
@@ -465,18 +496,26 @@ template <class T, class MD> struct Step {
     // always runs the first sweep, also in the rare substep in which no lane of the wave has a row (all weights
     // zero then: the sweep is the unconstrained solve): a test for that case is a branch on every substep.
     static MPPI_HD void constraint_forces(const T (&M)[NV][NV], const T (&fs)[NV], const Rows& r, Active& act,
-                                          T (&fc)[NV], int& sweeps_out, DampedFactor& damped) {
+                                          T (&ftot)[NV], int& sweeps_out, DampedFactor& damped) {
         if constexpr (!has_rows()) {
-            static_for<NV>([&](auto Ic) { fc[Ic] = T(0); });
+            static_for<NV>([&](auto Ic) { ftot[Ic] = fs[Ic]; });
             factor_damped(M, damped);
             sweeps_out = 0;
         } else {
             int sweeps = 0;
             // active weight of every row: its D while active, 0 while inactive or absent
-            T dg[NV], dc = sel(act.idle[NV] > T(0), T(0), r.Dc);
-            static_for<NV>([&](auto Ic) { dg[Ic] = sel(act.idle[Ic] > T(0), T(0), r.Dl[Ic]); });
-            T acc[NV], tl[NV], resc = T(0);
-            static_for<NV>([&](auto Ic) { tl[Ic] = T(0); });
+            Pair<T> dgp[NP];
+            T dc = sel(act.idle_contact > T(0), T(0), r.Dc);
+            static_for<NP>([&](auto Pc) {
+                dgp[Pc] = make_pair_of(sel(act.idle[Pc][0] > T(0), T(0), r.Dl[Pc][0]), sel(act.idle[Pc][1] > T(0), T(0), r.Dl[Pc][1]));
+            });
+            Pair<T> fsp[NP], tlp[NP];
+            static_for<NP>([&](auto Pc) {
+                constexpr int i1 = (2 * Pc + 1 < NV) ? 2 * Pc + 1 : 2 * Pc;
+                fsp[Pc] = make_pair_of(fs[2 * Pc], fs[i1]);
+                tlp[Pc] = make_pair_of(T(0), T(0));
+            });
+            T acc[NV], dg[NV], resc = T(0);
             T hb[NV];
             static_for<NV>([&](auto Ic) { hb[Ic] = T(MD::INTEGRATOR == 0 ? MD::H * MD::damping[Ic] : 0.0); });
             // the sweeps exist twice, with and without the contact row, chosen once per substep: a taken
@@ -488,15 +527,19 @@ template <class T, class MD> struct Step {
                 auto settle = [&](auto Grow) -> Mask<T> {
                     constexpr bool GROW = decltype(Grow)::value;
                     Mask<T> changed{};
-                    static_for<NV>([&](auto Ic) {
-                        constexpr int i = Ic;
-                        if constexpr (MD::limited[i] != 0) {
-                            tl[i] = acc[i] - r.sal[i];
-                            const T nd = sel(tl[i] * r.xs[i] > T(0), r.Dl[i], GROW ? dg[i] : T(0));
-                            MPPI_SWEEP_TRACE(sweeps, i, nd != dg[i]);
-                            changed |= (nd != dg[i]);
-                            dg[i] = nd;
-                        }
+                    static_for<NP>([&](auto Pc) {
+                        constexpr int i1 = (2 * Pc + 1 < NV) ? 2 * Pc + 1 : 2 * Pc;
+                        tlp[Pc] = make_pair_of(acc[2 * Pc], acc[i1]) - r.sal[Pc];
+                        const Pair<T> side = tlp[Pc] * r.xs[Pc];
+                        static_for<(i1 != 2 * Pc) ? 2 : 1>([&](auto Hc) {
+                            constexpr int h = Hc, i = 2 * Pc + h;
+                            if constexpr (MD::limited[i] != 0) {
+                                const T nd = sel(side[h] > T(0), r.Dl[Pc][h], GROW ? dgp[Pc][h] : T(0));
+                                MPPI_SWEEP_TRACE(sweeps, i, nd != dgp[Pc][h]);
+                                changed |= (nd != dgp[Pc][h]);
+                                dgp[Pc][h] = nd;
+                            }
+                        });
                     });
                     if constexpr (WC) {
                         T ja = T(0);
@@ -509,8 +552,13 @@ template <class T, class MD> struct Step {
                     }
                     return changed;
                 };
+                // right-hand side and diagonal of the current set, handed to the solver as single values
                 auto right_hand_side = [&]() {
-                    static_for<NV>([&](auto Ic) { acc[Ic] = fs[Ic] + dg[Ic] * r.sal[Ic]; });
+                    static_for<NP>([&](auto Pc) {
+                        const Pair<T> b = fsp[Pc] + dgp[Pc] * r.sal[Pc];
+                        acc[2 * Pc] = b[0]; dg[2 * Pc] = dgp[Pc][0];
+                        if constexpr (2 * Pc + 1 < NV) { acc[2 * Pc + 1] = b[1]; dg[2 * Pc + 1] = dgp[Pc][1]; }
+                    });
                     if constexpr (WC) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
                 };
                 sweeps = 1;
@@ -551,15 +599,15 @@ template <class T, class MD> struct Step {
                         }
                     }
                 }
-                // force of every active row on its joint
-                static_for<NV>([&](auto Ic) {
-                    constexpr int i = Ic;
-                    if constexpr (MD::limited[i] != 0) fc[i] = -dg[i] * tl[i];
-                    else fc[i] = T(0);
+                // smooth force plus the force of every active row on its joint
+                static_for<NP>([&](auto Pc) {
+                    const Pair<T> f = fsp[Pc] - dgp[Pc] * tlp[Pc];
+                    ftot[2 * Pc] = f[0];
+                    if constexpr (2 * Pc + 1 < NV) ftot[2 * Pc + 1] = f[1];
                 });
                 if constexpr (WC) {
                     const T f = -dc * resc;
-                    static_for<NV>([&](auto Ic) { fc[Ic] += r.Jc[Ic] * f; });
+                    static_for<NV>([&](auto Ic) { ftot[Ic] += r.Jc[Ic] * f; });
                 }
             };
             if constexpr (MD::contact_link >= 0) {
@@ -569,8 +617,8 @@ template <class T, class MD> struct Step {
                 sweep_all(std::false_type{});
             }
             // the weight withheld from every row: positive for the inactive ones, zero for active and absent rows
-            static_for<NV>([&](auto Ic) { act.idle[Ic] = r.Dl[Ic] - dg[Ic]; });
-            act.idle[NV] = r.Dc - dc;
+            static_for<NP>([&](auto Pc) { act.idle[Pc] = r.Dl[Pc] - dgp[Pc]; });
+            act.idle_contact = r.Dc - dc;
             sweeps_out = sweeps;
         }
     }
@@ -620,9 +668,7 @@ template <class T, class MD> struct Step {
         Rows rows;
         build_rows(q, fr, qd, rows);
         DampedFactor f;
-        T fc[NV];
-        constraint_forces(M, fs, rows, act, fc, sweeps_out, f);
-        static_for<NV>([&](auto Ic) { qacc[Ic] = fs[Ic] + fc[Ic]; });
+        constraint_forces(M, fs, rows, act, qacc, sweeps_out, f);
         if constexpr (LEAF_FIRST) leaf_first_apply(f.L, f.inv, qacc);
         else if constexpr (DUAL) dual_apply(f.D, f.inv, qacc);
         else chol_apply(f.P, f.inv, qacc);
@@ -858,35 +904,42 @@ template <class T, class MD> struct Step {
 
     // Impedance, regulariser and reference acceleration of one constraint row.
     //   xs  : signed violation (a limit row: q - clamp(q, lo, hi); the contact row: distance - margin, negative)
-    //   vel : velocity of the joint (limit row) or J qvel (contact row)
+    //   bvel: b times the velocity of the joint (limit row) or of J qvel (contact row)
     //   D   : 1 / R, R = (1 - d) / d * invweight
-    //   sa  : reference acceleration -b vel - k d xs, in the coordinates vel and xs are given in
+    //   sa  : reference acceleration -b vel - k d xs, in the coordinates bvel and xs are given in
     // The impedance d rises from d0 to dmax over the ramp u = |xs| / width in [0, 1]: y(u) = u^2 / mid below mid,
     // 1 - (1 - u)^2 / (1 - mid) above.  For mid = 1/2 the two branches are one expression,
-    // y = 1/2 + 2 z (1 - |z|) with z = u - 1/2, which needs no comparison; 1 - d is formed from the same product
-    // (not by subtracting d from 1: d is within 5 % of 1 and the difference would lose four bits).
-    static MPPI_HD void row_constants(T xs, T vel, T invweight, T& D, T& sa) {
+    // y = 1/2 + 2 p with p = z (1 - |z|), z = u - 1/2, which needs no comparison (ramp_product: absolute values are
+    // free operand modifiers of single instructions, so this part is not done in pairs); d and 1 - d are both
+    // formed from p (not 1 - d by subtracting d from 1: d is within 5 % of 1 and the difference would lose four bits).
+    static constexpr bool RAMP_ONE_EXPRESSION = MD::solimp[3] == 0.5 && MD::solimp[4] == 2.0;
+    static MPPI_HD T ramp_product(T xs) {
+        const T z = min_t(abs_t(xs) * T(1.0 / MD::solimp[2]) - T(0.5), T(0.5));
+        return z - abs_t(z) * z;
+    }
+    // (E: T, or a pair of rows)
+    template <class E> static MPPI_HD void row_from_ramp(E p, E xs, E bvel, E invweight, E& D, E& sa) {
+        constexpr double half_rise = 0.5 * (MD::solimp[1] - MD::solimp[0]);
+        const E imp = T(MD::solimp[0] + half_rise) + T(4.0 * half_rise) * p;
+        const E omi = T(1.0 - MD::solimp[0] - half_rise) - T(4.0 * half_rise) * p;
+        sa = -bvel - T(MD::solref_k) * (imp * xs);
+        D = imp * rcp_t(omi * invweight);
+    }
+    static MPPI_HD void row_constants(T xs, T bvel, T invweight, T& D, T& sa) {
         static_assert(MD::solimp[4] == 2.0, "impedance power other than 2 is not compiled in");
-        const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]);
-        T imp, omi;
-        if constexpr (MD::solimp[3] == 0.5) {
-            const T z = min_t(abs_t(xs) * T(1.0 / MD::solimp[2]) - T(0.5), T(0.5));
-            const T p = z * (T(1) - abs_t(z));
-            constexpr double half_rise = 0.5 * (MD::solimp[1] - MD::solimp[0]);
-            imp = T(MD::solimp[0] + half_rise) + T(4.0 * half_rise) * p;
-            omi = T(1.0 - MD::solimp[0] - half_rise) - T(4.0 * half_rise) * p;
+        if constexpr (RAMP_ONE_EXPRESSION) {
+            row_from_ramp(ramp_product(xs), xs, bvel, invweight, D, sa);
         } else {
-            const T mid = T(MD::solimp[3]);
+            const T d0 = T(MD::solimp[0]), dmax = T(MD::solimp[1]), mid = T(MD::solimp[3]);
             const T u = min_t(abs_t(xs) * T(1.0 / MD::solimp[2]), T(1));
             const T w = T(1) - u;
             const T ylo = u * u * T(1.0 / MD::solimp[3]);
             const T yhi = T(1) - w * w * T(1.0 / (1.0 - MD::solimp[3]));
             const T y = sel(u <= mid, ylo, yhi);
-            imp = d0 + y * (dmax - d0);
-            omi = T(1) - imp;
+            const T imp = d0 + y * (dmax - d0);
+            sa = -bvel - T(MD::solref_k) * (imp * xs);
+            D = imp * rcp_t((T(1) - imp) * invweight);
         }
-        sa = -T(MD::solref_b) * vel - T(MD::solref_k) * (imp * xs);
-        D = imp * rcp_t(omi * invweight);
     }
 
     // ---- dense solver -----------------------------------------------------------------------------
@@ -1017,7 +1070,6 @@ template <class T, class MD> struct Step {
                 b[j] *= inv1[j];
                 static_for<NV - 1 - j>([&](auto In) { constexpr int i = j + 1 + In; b[i] -= A.a[i][j][0] * b[j]; });
             }
-            sched_fence();
         });
         if constexpr (SOLVE) {
             static_for<NV>([&](auto Kn) {

@@ -466,7 +466,7 @@ template <class T, class MD> struct Step {
     struct DualSystem { Pair<T> a[NV][NV]; };
     // Models with constraint rows factor M + h B next to the first sweep's system, entry by entry in pairs.
     static constexpr bool DUAL = has_rows() && !LEAF_FIRST;
-    struct DampedFactor {                                // inv[j] = 1 / L_jj
+    struct DampedFactor {                                // inv[j] = 1 / D_jj (root-first), 1 / L_jj (leaf-first)
         DualSystem D;        // half [1]: root-first factor, made next to the constraint system's
         PackedSystem P;      // root-first factor (row pairs)
         T L[NV][NV];         // leaf-first factor of a branching model
@@ -943,9 +943,11 @@ template <class T, class MD> struct Step {
     }
 
     // ---- dense solver -----------------------------------------------------------------------------
-    // Cholesky, written right-looking: a finished column is applied to the rest of the matrix at once,
-    // and the forward substitution rides along as one more row.  Every sum runs in the order of the
-    // textbook left-looking form.  inv[j] = 1 / L_jj.
+    // A = L D L^T with unit lower-triangular L, written right-looking: a finished column is applied to the rest
+    // of the matrix at once, and the forward substitution rides along as one more row.  Every sum runs in the
+    // order of the textbook left-looking form.  inv[j] = 1 / D_jj.  (Against Cholesky: a reciprocal instead of a
+    // reciprocal square root per pivot, and one scaling by 1 / D per solve instead of a scaling by 1 / L_jj in
+    // each of the two substitutions.)
     // Every column is held as pairs of rows {2p, 2p+1}: scaling a column, applying it to a later column and
     // the forward substitution are one packed instruction per pair with the multiplier broadcast (fp64: two
     // instructions, as before).  Halves above the diagonal (and row NV of an odd NV) carry unused values:
@@ -974,14 +976,19 @@ template <class T, class MD> struct Step {
             });
         });
     }
-    // column j of the factor (in place), applied to the columns right of it
+    // column j of the factor (in place), applied to the columns right of it: A_ik -= L_ij A_kj
     template <int j>
     static MPPI_HD void eliminate_column(PackedSystem& A, T (&inv)[NV]) {
-        inv[j] = rsqrt_t(A.col[j][j / 2][j % 2]);
-        static_for<NP - (j + 1) / 2>([&](auto Pn) { constexpr int p = (j + 1) / 2 + Pn; A.col[j][p] *= inv[j]; });
+        inv[j] = rcp_t(A.col[j][j / 2][j % 2]);
+        Pair<T> raw[NP];                    // the column before scaling: A_kj = L_kj D_jj
+        static_for<NP - (j + 1) / 2>([&](auto Pn) {
+            constexpr int p = (j + 1) / 2 + Pn;
+            raw[p] = A.col[j][p];
+            A.col[j][p] *= inv[j];
+        });
         static_for<NV - 1 - j>([&](auto Kn) {
             constexpr int k = j + 1 + Kn;
-            const Pair<T> m = splat_half<k % 2>(A.col[j][k / 2]);
+            const Pair<T> m = splat_half<k % 2>(raw[k / 2]);
             static_for<NP - k / 2>([&](auto Pn) { constexpr int p = k / 2 + Pn; A.col[k][p] -= A.col[j][p] * m; });
         });
     }
@@ -993,34 +1000,35 @@ template <class T, class MD> struct Step {
             else bp[p] = half_pair<0>(b[2 * p]);
         });
     }
-    // forward substitution step j: y_j is final, later rows accumulate
+    // forward substitution step j (L y = b): y_j is final, later rows accumulate
+    // (the pair that holds row j itself is updated along with the rows below it and is not read again)
     template <int j>
-    static MPPI_HD void forward_column(const PackedSystem& L, const T (&inv)[NV], Pair<T> (&bp)[NP], T (&y)[NV]) {
-        y[j] = bp[j / 2][j % 2] * inv[j];
+    static MPPI_HD void forward_column(const PackedSystem& L, Pair<T> (&bp)[NP], T (&y)[NV]) {
+        y[j] = bp[j / 2][j % 2];
         static_for<NP - (j + 1) / 2>([&](auto Pn) { constexpr int p = (j + 1) / 2 + Pn; bp[p] -= L.col[j][p] * y[j]; });
     }
-    // x_i = (y_i - sum_{k > i} L_ki x_k) / L_ii, last row first; y is overwritten with x
+    // z = y / D, then x_i = z_i - sum_{k > i} L_ki x_k, last row first; y is overwritten with x
     static MPPI_HD void back_substitute(const PackedSystem& L, const T (&inv)[NV], T (&y)[NV]) {
         static_for<NV>([&](auto Kn) {
             constexpr int i = NV - 1 - Kn;
-            T acc = y[i];
+            T acc = y[i] * inv[i];
             static_for<NV - 1 - i>([&](auto Rn) { constexpr int k = NV - 1 - Rn; acc -= L.col[i][k / 2][k % 2] * y[k]; });
-            y[i] = acc * inv[i];
+            y[i] = acc;
         });
     }
 
-    // Cholesky factor of M + diag(dg) + dc * Jc Jc^T; M (lower triangle) is read, not modified.
+    // L D L^T factor of M + diag(dg) + dc * Jc Jc^T; M (lower triangle) is read, not modified.
     template <bool CONTACT>
     static MPPI_HD void chol_factor(const T (&M)[NV][NV], const T (&dg)[NV], T dc, const T (&Jc)[NV], PackedSystem& L,
                                     T (&inv)[NV]) {
         build_system<CONTACT>(M, dg, dc, Jc, L);
         static_for<NV>([&](auto Jn) { eliminate_column<Jn>(L, inv); });
     }
-    // b <- (L L^T)^-1 b
+    // b <- (L D L^T)^-1 b
     static MPPI_HD void chol_apply(const PackedSystem& L, const T (&inv)[NV], T (&b)[NV]) {
         Pair<T> bp[NP];
         pack_rhs(b, bp);
-        static_for<NV>([&](auto Jn) { forward_column<Jn>(L, inv, bp, b); });
+        static_for<NV>([&](auto Jn) { forward_column<Jn>(L, bp, b); });
         back_substitute(L, inv, b);
     }
     // solve (M + diag(dg) + dc * Jc Jc^T) x = b; b is overwritten with x
@@ -1033,7 +1041,7 @@ template <class T, class MD> struct Step {
         pack_rhs(b, bp);
         static_for<NV>([&](auto Jn) {
             eliminate_column<Jn>(L, inv);
-            forward_column<Jn>(L, inv, bp, b);
+            forward_column<Jn>(L, bp, b);
         });
         back_substitute(L, inv, b);
     }
@@ -1058,37 +1066,40 @@ template <class T, class MD> struct Step {
         T inv1[NV];
         static_for<NV>([&](auto Jn) {
             constexpr int j = Jn;
-            inv1[j] = rsqrt_t(A.a[j][j][0]);
-            inv2[j] = rsqrt_t(A.a[j][j][1]);
+            inv1[j] = rcp_t(A.a[j][j][0]);
+            inv2[j] = rcp_t(A.a[j][j][1]);
             const Pair<T> ip = make_pair_of(inv1[j], inv2[j]);
-            static_for<NV - 1 - j>([&](auto In) { A.a[j + 1 + In][j] *= ip; });
+            Pair<T> raw[NV];                // the column before scaling: A_kj = L_kj D_jj
+            static_for<NV - 1 - j>([&](auto In) {
+                constexpr int i = j + 1 + In;
+                raw[i] = A.a[i][j];
+                A.a[i][j] *= ip;
+            });
             static_for<NV - 1 - j>([&](auto Kn) {
                 constexpr int k = j + 1 + Kn;
-                static_for<NV - k>([&](auto In) { constexpr int i = k + In; A.a[i][k] -= A.a[i][j] * A.a[k][j]; });
+                static_for<NV - k>([&](auto In) { constexpr int i = k + In; A.a[i][k] -= A.a[i][j] * raw[k]; });
             });
             if constexpr (SOLVE) {
-                b[j] *= inv1[j];
                 static_for<NV - 1 - j>([&](auto In) { constexpr int i = j + 1 + In; b[i] -= A.a[i][j][0] * b[j]; });
             }
         });
         if constexpr (SOLVE) {
+            static_for<NV>([&](auto Kn) { b[Kn] *= inv1[Kn]; });
             static_for<NV>([&](auto Kn) {
                 constexpr int k = NV - 1 - Kn;
-                b[k] *= inv1[k];
                 static_for<k>([&](auto In) { constexpr int i = k - 1 - In; b[i] -= A.a[k][i][0] * b[k]; });
             });
         }
     }
-    // b <- (L L^T)^-1 b with the factor of system 2
+    // b <- (L D L^T)^-1 b with the factor of system 2
     static MPPI_HD void dual_apply(const DualSystem& A, const T (&inv)[NV], T (&b)[NV]) {
         static_for<NV>([&](auto Jn) {
             constexpr int j = Jn;
-            b[j] *= inv[j];
             static_for<NV - 1 - j>([&](auto In) { constexpr int i = j + 1 + In; b[i] -= A.a[i][j][1] * b[j]; });
         });
+        static_for<NV>([&](auto Kn) { b[Kn] *= inv[Kn]; });
         static_for<NV>([&](auto Kn) {
             constexpr int k = NV - 1 - Kn;
-            b[k] *= inv[k];
             static_for<k>([&](auto In) { constexpr int i = k - 1 - In; b[i] -= A.a[k][i][1] * b[k]; });
         });
     }

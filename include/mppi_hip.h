@@ -11,9 +11,15 @@
  * error, -8 host exception such as out of memory; nothing is thrown across
  * this boundary); the message is available from mppi_last_error() (thread local,
  * valid until the next call on that thread).  Host pointers are copied before
- * the call returns.  `stream` arguments take a hipStream_t (or NULL for the
+ * the call returns.  The array arguments of mppi_set_start_state,
+ * mppi_set_base_actions, mppi_set_reference, mppi_upload_noise,
+ * mppi_upload_actions and mppi_shift may also be device memory (for instance a
+ * torch tensor's data_ptr()): the library looks the address up and copies from
+ * where it lies.  `stream` arguments take a hipStream_t (or NULL for the
  * planner's own stream).  A planner is not re-entrant; distinct planners may
- * be driven from distinct host threads.
+ * be driven from distinct host threads.  A model handle may be shared between
+ * threads: mppi_env_step / mppi_env_forward calls on one model and device take
+ * turns inside the library (their own stream, no device-wide synchronisation).
  */
 #ifndef MPPI_HIP_H
 #define MPPI_HIP_H
@@ -26,7 +32,7 @@ extern "C" {
 #endif
 
 #define MPPI_MAXV 32
-#define MPPI_ABI_VERSION 6
+#define MPPI_ABI_VERSION 7
 #define MPPI_LOG_CAP 4096
 #define MPPI_NOALLOC_MAX_K 262144   /* most samples mppi_update_from_returns_noalloc accepts */
 
@@ -51,7 +57,11 @@ enum {
 
 enum {
     MPPI_STATUS_NONFINITE = 1,  /* a rollout returned NaN or infinity                                             */
-    MPPI_STATUS_SWEEP_CAP = 2   /* an active-set solve of the constraint rows stopped at cfg.sweep_cap sweeps     */
+    MPPI_STATUS_SWEEP_CAP = 2,  /* an active-set solve of the constraint rows stopped at cfg.sweep_cap sweeps     */
+    MPPI_STATUS_REF_END = 4     /* a tracking / cooling reward asked for a row past the end of the reference      */
+                                /* trajectory (IndexError in trajopt/envs/reacher_env.py:61,75); the last row was */
+                                /* used.  Calls return -5 instead whenever the host already knows the time step;   */
+                                /* the bit covers steps whose time step advanced on the device (mppi_plan).        */
 };
 
 /* Flat model: one link per hinge or slide joint (welded bodies merged), the data the reference hands
@@ -218,6 +228,11 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
  * inside every worker, trajopt/utils.py:135-139). */
 int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream);
 int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
+/* What one `MPPI.train_step` hands back to its caller (trajopt/algos/mppi.py:74-89), after mppi_advance,
+ * mppi_advance_noise or mppi_plan: the newest log row of every planner (P x (3M+7) doubles, layout as in
+ * mppi_advance) and the shifted act_sequence (P x H*M doubles), as two copies behind the planner's stream and one
+ * wait.  Either pointer may be NULL. */
+int mppi_read_step(mppi_planner* p, double* rows_out, double* act_seq_out);
 
 int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);
 

@@ -189,6 +189,78 @@ def test_train_step_matches_oracle_loop(oracle_sim, dtype):
     assert len(ag2.sol_state) == steps + 2
 
 
+def test_train_step_follows_what_the_caller_changes_between_steps(oracle_sim):
+    """`train_step` keeps start state and act_sequence on the device from one call to the next.  A caller who writes to
+    `act_sequence`, to `sol_state[-1]` or to the environment between two calls must get the step the reference would
+    take from what the attributes hold then: every step is checked against the oracle restarted from the agent's own
+    attributes as they were when the step was asked for."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    goal = np.array([0.05, -0.05, 0.1])
+    e = get_environment('reacher_7dof')
+    e.reset_model(seed=3, goal=goal)
+    H, K, niter, seed = 12, 48, 2, 21
+    ag = MPPI(e, H=H, paths_per_cpu=K, kappa=25.0, gamma=0.98, mean=np.zeros(7), filter_coefs=FILTER, default_act='mean',
+              seed=seed, dtype="f64")
+    rs = np.random.RandomState(5)
+    for step in range(14):
+        if step == 3:
+            ag.act_sequence[2:5] += 0.3 * rs.randn(3, 7)              # in place
+        if step == 5:
+            ag.act_sequence = 0.1 * rs.randn(H, 7)                    # rebound
+        if step == 7:
+            ag.sol_state[-1]['qp'][:] = ag.sol_state[-1]['qp'] + 0.05 * rs.randn(7)      # in place
+        if step == 9:
+            ag.sol_state[-1] = dict(qp=0.2 * rs.randn(7), qv=rs.randn(7), target_pos=goal.copy(), timestep=ag.sol_state[-1]['timestep'])
+        if step == 11:
+            e.set_env_state(dict(qp=np.zeros(7), qv=np.ones(7), target_pos=goal.copy(), timestep=40))     # advance_time re-seats the env
+            e.step(np.ones(7))
+        s0, seq = {k: np.copy(v) for k, v in ag.sol_state[-1].items()}, ag.act_sequence.copy()
+        t = len(ag.sol_state) - 1
+        ag.train_step(niter=niter, goal=goal)
+        eps = ref_mppi.filter_noise(ref_mppi.all_raw_normals(seed + t, K, 1, H, 7), FILTER)
+        for _ in range(niter):
+            R = oracle_sim.rollout(s0["qp"], s0["qv"], goal, int(s0["timestep"]), seq + eps, gamma=0.98)
+            seq = ref_mppi.update(seq + eps, R, 25.0)
+        q, v, obs, r, _ = oracle_sim.env_step(s0["qp"], s0["qv"], goal, seq[0], int(s0["timestep"]))
+        assert np.abs(ag.sol_state[-1]["qp"] - q).max() < 1e-8 and np.abs(ag.sol_state[-1]["qv"] - v).max() < 1e-8, step
+        assert abs(ag.sol_reward[-1] - r) < 1e-8 and ag.sol_state[-1]["timestep"] == s0["timestep"] + 1
+        assert np.abs(ag.act_sequence - ref_mppi.shift(seq, "mean", np.zeros(7))).max() < 1e-6, step
+        # the environment is left where `set_env_state(sol_state[-2]); step(act_sequence[0])` leaves it
+        st = e.get_env_state()
+        assert np.array_equal(st["qp"], ag.sol_state[-1]["qp"]) and st["timestep"] == ag.sol_state[-1]["timestep"]
+        assert np.abs(ag.sol_obs[-1][:20] - np.r_[q, v, obs[14:17], goal]).max() < 1e-8
+        assert abs(ag.sol_obs[-1][20] - np.linalg.norm(obs[14:17] - goal)) < 1e-8 and np.abs(e.data.ctrl - seq[0]).max() < 1e-6
+    assert len(ag.sol_act) == 14 and np.all(np.array(ag.sol_act)[:10] == 0) and np.any(ag.sol_act[12] != 0)
+
+
+@pytest.mark.parametrize("noise", ["philox", "host"])
+def test_resident_train_step_equals_the_step_by_step_one(noise):
+    """The device-resident step (state, act_sequence and the real environment's step stay on the device) against the
+    same planner driven piece by piece with everything sent again at every call (`advance_time` on the host side, which
+    an `act_sequence=` argument asks for): same trajectory, bit for bit in fp64."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    goal = (0.05, 0.0, 0.05)
+    logs = []
+    for resident in (True, False):
+        e = get_environment('reacher_7dof')
+        e.reset_model(seed=2, goal=goal)
+        ag = MPPI(e, H=10, paths_per_cpu=64, kappa=25.0, filter_coefs=FILTER, default_act='repeat', seed=4, noise=noise,
+                  dtype="f64")
+        for step in range(6):
+            if resident:
+                ag.train_step(niter=2)
+            else:
+                # the piecewise path: iterations on the device, then advance_time through the environment object
+                ag._plan_on_device(ag.seed + len(ag.sol_state) - 1, 2)
+                ag.advance_time()
+        logs.append((np.array([s["qp"] for s in ag.sol_state]), np.array(ag.sol_reward), ag.act_sequence.copy(),
+                     np.array(ag.sol_obs[1:]), np.array(ag.sol_act)))
+    for a, b in zip(*logs):
+        assert np.array_equal(a, b)
+
+
 def test_update_with_paths_and_critic():
     import torch
     from trajopt.algos.mppi import MPPI

@@ -70,6 +70,7 @@ _PROTOS = {
     "mppi_advance_noise": (C.c_int, [_vp, C.c_uint64, _vp]),
     "mppi_plan": (C.c_int, [_vp, _u64, _i32, _i32, _vp]),
     "mppi_read_log": (C.c_int, [_vp, _i32, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "mppi_read_step": (C.c_int, [_vp, _vp, _vp]),
     "mppi_upload_actions": (C.c_int, [_vp, _vp, _vp]),
     "mppi_rollout": (C.c_int, [_vp, _vp]),
     "mppi_iterate": (C.c_int, [_vp, _i32, _vp]),

@@ -1,9 +1,13 @@
 """`MPPI` with the reference's constructor, methods and attributes
 (trajopt/algos/mppi.py:15-196), planning on the GPU.
 
-`train_step` keeps the whole iteration on the device: the K perturbed rollouts, their
-discounted returns, the exponentiated-return weights and the weighted action update run as
-kernels behind `mppi_iterate`; only the (H, m) `act_sequence` comes back.  The quirks that
+`train_step` keeps the whole planning step on the device: the K perturbed rollouts, their
+discounted returns, the exponentiated-return weights, the weighted action update, the step of
+the real environment with the first action and the horizon shift run as kernels behind
+`mppi_plan` (device noise) or `mppi_iterate` + `mppi_advance` (uploaded numpy noise); one log
+row and the (H, m) `act_sequence` come back.  State and `act_sequence` stay on the device from
+one call to the next and are sent again only when the caller has changed `sol_state[-1]` or
+`act_sequence` in between (they are compared with what the device was last seen to hold).  The quirks that
 callers observe are kept: every iteration of one `train_step` sees the same noise
 (seed + t), worker streams overlap (seed + i*paths_per_cpu), the denominator carries 1e-6,
 `sol_act` logs zeros for the first ten steps, `update` rebinds `act_sequence` while
@@ -76,6 +80,8 @@ class MPPI(Trajectory):
         self._planner_key = None
         self._ahead = None              # (key, numpy state record) of host noise drawn for the next planning step
         self.draw_ahead = True
+        self._dev_state = None          # (planner id, qp, qv, target_pos, timestep) the device planner holds ...
+        self._dev_seq = None            # ... and its act_sequence, as of the last step read back
 
     # ---- pickling: device handles are dropped and rebuilt on demand -------------------------
     def __getstate__(self):
@@ -83,6 +89,8 @@ class MPPI(Trajectory):
         d.pop('_planner', None)
         d.pop('_planner_key', None)
         d.pop('_ahead', None)
+        d.pop('_dev_state', None)
+        d.pop('_dev_seq', None)
         return d
 
     def __setstate__(self, d):
@@ -92,6 +100,8 @@ class MPPI(Trajectory):
         self._planner = None
         self._planner_key = None
         self._ahead = None
+        self._dev_state = None
+        self._dev_seq = None
         self.__dict__.setdefault('draw_ahead', True)
 
     # ---- device planner -----------------------------------------------------------------
@@ -104,6 +114,7 @@ class MPPI(Trajectory):
             if self._planner is not None:
                 self._planner.close()
             self._ahead = None
+            self._dev_state = self._dev_seq = None
             model = DeviceModel.get(_KERNEL_ENVS[self.env.env_name])
             self._planner = DevicePlanner(model, self.paths_per_cpu * self.num_cpu, self.H, kappa=self.kappa,
                                           gamma=self.gamma, sigma=sig, betas=(b0, b1, b2), mean=self.mean,
@@ -146,6 +157,10 @@ class MPPI(Trajectory):
         t = len(self.sol_state) - 1
         weights = _critic_weights(critic, dim)
         if self.env.env_name in _KERNEL_ENVS and (critic is None or weights is not None):
+            if act_sequence is None and self._real_env_steps_like_the_rollouts():
+                # the whole step, the real environment's included, without leaving the device
+                self._plan_on_device(self.seed + t, niter, dim if critic is not None else 0, weights, advance=True)
+                return []
             self._plan_on_device(self.seed + t, niter, dim if critic is not None else 0, weights)
         else:
             # an arbitrary Python critic can only be evaluated on the host: rollouts come back as paths
@@ -157,7 +172,33 @@ class MPPI(Trajectory):
         return []
 
     # ---- device-resident iteration ------------------------------------------------------
-    def _plan_on_device(self, seed, niter, critic_dim=0, critic_weights=None):
+    def _real_env_steps_like_the_rollouts(self):
+        """True if the device planner's own fp64 step of the real environment is what `self.env.step` would do: a
+        plain reacher whose reward is the one the rollouts are scored with (the planner logs that reward)."""
+        from ..envs.reacher_env import Reacher7DOFEnv
+        e = self.env
+        if type(e) is not Reacher7DOFEnv:
+            return False
+        rt, reference = rollout_objective(e.env_name, self.reward_type, self.reference)
+        rt_env = e.reward_type if e.reward_type in ('sparse', 'tracking', 'cooling') else 'dense'
+        if rt != rt_env:
+            return False
+        if rt in ('tracking', 'cooling'):
+            if e.reference is None or reference is None:
+                return False
+            if e.reference is not reference and not np.array_equal(np.asarray(e.reference), np.asarray(reference)):
+                return False
+        return True
+
+    def _device_holds(self, p, s):
+        d = self._dev_state
+        return (d is not None and d[0] == id(p) and d[4] == s['timestep'] and np.array_equal(d[1], s['qp'])
+                and np.array_equal(d[2], s['qv']) and np.array_equal(d[3], s['target_pos']))
+
+    def _plan_on_device(self, seed, niter, critic_dim=0, critic_weights=None, advance=False):
+        """niter iterations on the device from sol_state[-1] and act_sequence.  advance: also `advance_time` there
+        (real-env step with the new act_sequence[0], logs, shift); otherwise act_sequence is read back and the
+        caller advances."""
         s = self.sol_state[-1]
         H = self.H
         rt, reference = rollout_objective(self.env.env_name, self.reward_type, self.reference)
@@ -169,13 +210,20 @@ class MPPI(Trajectory):
                 raise IndexError("index %d is out of bounds for axis 0 with size %d"
                                  % (int(s['timestep']) + H, len(reference)))
         p = self._device_planner()
-        p.set_start_state(s['qp'], s['qv'], s['target_pos'], s['timestep'])
+        if not self._device_holds(p, s):
+            p.set_start_state(s['qp'], s['qv'], s['target_pos'], s['timestep'])
         p.set_reference(reference if tracked else None, self.env.alpha)
-        p.set_base_actions(self.act_sequence)
+        if self._dev_seq is None or self._dev_seq[0] != id(p) or not np.array_equal(self._dev_seq[1], self.act_sequence):
+            p.set_base_actions(self.act_sequence)
+        self._dev_state = self._dev_seq = None           # until the outcome of this step has been read back
         p.set_critic(critic_dim, critic_weights)         # a no-op while dim and weights stay what they were
         if self.noise == 'philox':
-            p.generate_noise(seed)
-            p.iterate(niter)
+            if advance:
+                # the device keys its stream with seed argument + time step of its state; one launch of the captured step
+                p.plan(seed - int(s['timestep']), niter, 1)
+            else:
+                p.generate_noise(seed)
+                p.iterate(niter)
         else:
             # The host stream of planning step t + 1 depends on nothing but its seed, so it is drawn while the device
             # works on step t (the staging buffer is free again once the upload has returned).  What was drawn ahead
@@ -192,10 +240,30 @@ class MPPI(Trajectory):
                 _set_numpy_state(state)
             p.upload_noise(buf)
             p.iterate(niter)
+            if advance:
+                p.advance()
             if self.draw_ahead and 0 <= seed + 1 < 2 ** 32:
                 _, state = all_worker_normals(seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m, out=buf, defer_state=True)
                 self._ahead = ((id(p), seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m), state)
-        self.act_sequence = p.act_sequence()
+        if not advance:
+            self.act_sequence = p.act_sequence()
+            self._dev_seq = (id(p), self.act_sequence.copy())
+            self._dev_state = (id(p), np.array(s['qp'], dtype=float), np.array(s['qv'], dtype=float),
+                               np.array(s['target_pos'], dtype=float), s['timestep'])
+            return
+        # `advance_time` (trajopt/algos/mppi.py:67-89) from the device's log row
+        row, seq = p.read_step()
+        nq, nv = p.nq, p.nv
+        q2, v2, hand, r, action = row[:nq], row[nq:nq + nv], row[nq + nv:nq + nv + 3], row[nq + nv + 6], row[nq + nv + 7:]
+        self.sol_act.append(np.zeros_like(action) if len(self.sol_act) < 10 else action.copy())
+        after = dict(qp=q2.copy(), qv=v2.copy(), target_pos=np.array(s['target_pos'], dtype=float), timestep=s['timestep'] + 1)
+        self.env._adopt_step(after, action, hand)
+        self.sol_state.append(self.env.get_env_state().copy())
+        self.sol_obs.append(self.env._get_obs(goal_dist=True))
+        self.sol_reward.append(float(r))
+        self.act_sequence = seq
+        self._dev_seq = (id(p), seq.copy())
+        self._dev_state = (id(p), after['qp'], after['qv'], after['target_pos'], after['timestep'])
 
     def _attach_critic_rewards(self, paths, critic, dim):
         """Terminal-value inputs by `dim` (trajopt/algos/mppi.py:134-159, 191)."""

@@ -190,6 +190,12 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     rp.alpha = T(st->alpha);
     rp.target[0] = T(st->target[0]); rp.target[1] = T(st->target[1]); rp.target[2] = T(st->target[2]);
     const int t0 = st->timestep, ref_len = LEAN ? 0 : st->ref_len;
+    // The reference indexes its trajectory with the time step after every env step (trajopt/envs/reacher_env.py:61,75)
+    // and raises IndexError past the end; here the index is held at the last row and the status word says so.
+    if constexpr (!LEAN) {
+        if (k == 0 && ref_len > 0 && t0 + H >= ref_len && (reward_type == REWARD_TRACKING || reward_type == REWARD_COOLING))
+            atomicOr(status, MPPI_STATUS_REF_END);
+    }
     const T gm = T(gamma);
     T ret = T(0), g = T(1);
     typename Step<T, MD>::Active act_rows;
@@ -305,7 +311,8 @@ template <class MD>
 __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st, double* __restrict__ base,
                                               const double* __restrict__ ref, int reward_type, int H, int tail_mode,
                                               const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                              int* __restrict__ log_count) {
+                                              int* __restrict__ log_count, double* __restrict__ last_row,
+                                              int* __restrict__ status) {
     constexpr int NV = MD::NV, NQ = MD::NQ;
     constexpr int ROW = NQ + 2 * NV + 7;
     constexpr int PER = 16;                       // H * NV <= 256 * PER
@@ -337,6 +344,8 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
         const int t0 = st->timestep, ref_len = st->ref_len;
         if (ref_len > 0) {
             int idx = t0 + 1;
+            if (idx >= ref_len && (reward_type == REWARD_TRACKING || reward_type == REWARD_COOLING))
+                atomicOr(status, MPPI_STATUS_REF_END);      // IndexError in the reference (trajopt/envs/reacher_env.py:61,75)
             idx = idx < ref_len ? idx : ref_len - 1;
             rr[0] = ref[3 * idx]; rr[1] = ref[3 * idx + 1]; rr[2] = ref[3 * idx + 2];
         }
@@ -347,11 +356,17 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
         const double r = Env<double, MD>::step(q, v, a, rp, rr, hand, am, ms);
         const int n = *log_count;
         double* row = log + (size_t)(n % log_cap) * ROW;
-        static_for<NQ>([&](auto Ic) { row[Ic] = q[Ic]; st->q[Ic] = q[Ic]; });
-        static_for<NV>([&](auto Ic) { row[NQ + Ic] = v[Ic]; row[NQ + NV + 7 + Ic] = a[Ic]; st->v[Ic] = v[Ic]; });
+        double* last = last_row + (size_t)pl * ROW;         // the newest row of every planner, side by side
+        static_for<NQ>([&](auto Ic) { row[Ic] = q[Ic]; last[Ic] = q[Ic]; st->q[Ic] = q[Ic]; });
+        static_for<NV>([&](auto Ic) {
+            row[NQ + Ic] = v[Ic]; row[NQ + NV + 7 + Ic] = a[Ic];
+            last[NQ + Ic] = v[Ic]; last[NQ + NV + 7 + Ic] = a[Ic];
+            st->v[Ic] = v[Ic];
+        });
         row[NQ + NV + 0] = hand.v[0]; row[NQ + NV + 1] = hand.v[1]; row[NQ + NV + 2] = hand.v[2];
         row[NQ + NV + 3] = rp.target[0]; row[NQ + NV + 4] = rp.target[1]; row[NQ + NV + 5] = rp.target[2];
         row[NQ + NV + 6] = r;
+        static_for<7>([&](auto Ic) { last[NQ + NV + Ic] = row[NQ + NV + Ic]; });
         st->timestep = t0 + 1;
         *log_count = n + 1;
     }
@@ -366,8 +381,9 @@ template <class MD>
 __global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
                                                       const double* __restrict__ ref, int reward_type, int H, int tail_mode,
                                                       const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                                      int* __restrict__ log_count) {
-    advance_block<MD>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
+                                                      int* __restrict__ log_count, double* __restrict__ last_row,
+                                                      int* __restrict__ status) {
+    advance_block<MD>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status);
 }
 // advance_kernel and, in the blocks behind the first of every planner, the Philox noise of the NEXT planning step
 // (stream key seed + next_step[planner], published by the rollouts of the current step): the noise does not depend
@@ -376,10 +392,11 @@ template <class T, class MD>
 __global__ void __launch_bounds__(256) advance_noise_kernel(DevState* __restrict__ st, double* __restrict__ base,
                                                             const double* __restrict__ ref, int reward_type, int H, int tail_mode,
                                                             const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                                            int* __restrict__ log_count, int K, int k_offset, uint32_t seed_lo,
+                                                            int* __restrict__ log_count, double* __restrict__ last_row,
+                                                            int* __restrict__ status, int K, int k_offset, uint32_t seed_lo,
                                                             uint32_t seed_hi, const int* __restrict__ next_step, FilterCoefs fc,
                                                             T* __restrict__ eps) {
-    if (blockIdx.x == 0) advance_block<MD>(blockIdx.y, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
+    if (blockIdx.x == 0) advance_block<MD>(blockIdx.y, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status);
     else noise_philox_block<T, MD::NV>(blockIdx.x - 1, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, next_step[blockIdx.y], 1, fc, eps);
 }
 
@@ -714,12 +731,12 @@ struct ModelOps {
     hipError_t (*noise_philox)(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st, int seed_from_state,
                                const FilterCoefs&, void* eps, hipStream_t);
     hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
-                          const double* mean, double* log, int log_cap, int* log_count, hipStream_t);
+                          const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
     hipError_t (*critic)(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t);
     hipError_t (*advance_noise)(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
-                                const double* mean, double* log, int log_cap, int* log_count, int K, int k_offset, uint64_t seed,
-                                const int* next_step, const FilterCoefs& fc, void* eps, hipStream_t);
+                                const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status,
+                                int K, int k_offset, uint64_t seed, const int* next_step, const FilterCoefs& fc, void* eps, hipStream_t);
     hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, int write_base, double* weights, double* base,
                               double* part, double* result, hipStream_t);
 };
@@ -816,23 +833,25 @@ static hipError_t launch_noise_philox(int dtype, int K, int H, int P, int k_offs
 }
 template <class MD>
 static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
-                                 const double* mean, double* log, int log_cap, int* log_count, hipStream_t s) {
-    hipLaunchKernelGGL((advance_kernel<MD>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count);
+                                 const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL((advance_kernel<MD>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap,
+                       log_count, last_row, status);
     return hipGetLastError();
 }
 template <class MD>
 static hipError_t launch_advance_noise(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P,
-                                       int tail_mode, const double* mean, double* log, int log_cap, int* log_count, int K,
-                                       int k_offset, uint64_t seed, const int* next_step, const FilterCoefs& fc, void* eps,
-                                       hipStream_t s) {
+                                       int tail_mode, const double* mean, double* log, int log_cap, int* log_count,
+                                       double* last_row, int* status, int K, int k_offset, uint64_t seed, const int* next_step,
+                                       const FilterCoefs& fc, void* eps, hipStream_t s) {
     const dim3 grid(1 + (K * MD::NV + 255) / 256, P), block(256);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((advance_noise_kernel<float, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, K, k_offset, lo, hi, next_step, fc, (float*)eps);
+                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (float*)eps);
     else
         hipLaunchKernelGGL((advance_noise_kernel<double, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, K, k_offset, lo, hi, next_step, fc, (double*)eps);
+                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (double*)eps);
     return hipGetLastError();
 }
 template <class MD>

@@ -267,8 +267,11 @@ static const RcclApi* rccl_api(std::string& why) {
 struct mppi_model {
     const ModelOps* ops;
     mppi_model_desc desc;
-    // per-device scratch of the single-step entry points (lazily allocated)
+    // Per-device scratch and stream of the single-step entry points (made on first use).  Calls on one device take
+    // turns (mu): environments of a process share the model handle and may be stepped from several host threads.
     double* d_io[16];
+    hipStream_t io_stream[16];
+    std::mutex mu[16];
 };
 
 struct mppi_planner {
@@ -298,6 +301,8 @@ struct mppi_planner {
     int critic_dim;        // 0: no critic
     double* d_log;         // [LOG_CAP][3M+7] real-env log ring of mppi_advance
     int* d_log_count;
+    double* d_last_row;    // [P][3M+7] the newest log row of every planner (mppi_read_step)
+    double* h_step;        // page-locked [P][3M+7 + H*M]: where mppi_read_step lands its two copies
     int* d_next_step;      // [P] index of the planning step after the one being rolled out
     bool noise_ahead;      // eps already holds the Philox noise of the coming planning step ...
     uint64_t noise_ahead_seed;   // ... drawn with this seed
@@ -324,6 +329,38 @@ struct mppi_planner {
 };
 
 static hipStream_t pick(mppi_planner* p, void* s) { return s ? (hipStream_t)s : p->stream; }
+
+// Input arrays may be host memory or device memory (a torch tensor's data_ptr()): bulk copies use hipMemcpyDefault,
+// which takes the direction from the addresses; the few small arrays the host itself has to look at come through here.
+static bool on_device(const void* ptr) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();            // an ordinary host pointer is unknown to the runtime: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+static int host_view(const double* src, size_t n, std::vector<double>& tmp, const double** out) {
+    if (!on_device(src)) { *out = src; return 0; }
+    tmp.resize(n);
+    HIP_OK(hipMemcpy(tmp.data(), src, n * 8, hipMemcpyDeviceToHost));
+    *out = tmp.data();
+    return 0;
+}
+
+// tracking / cooling rewards read reference[timestep + 1 .. timestep + steps]: the reference raises IndexError past
+// the end (trajopt/envs/reacher_env.py:61,75); -5 here, from the host's copy of the time step (kept in step with
+// device-resident advances)
+static int reference_covers(const mppi_planner* p, int steps) {
+    if (p->cfg.reward_type != REWARD_TRACKING && p->cfg.reward_type != REWARD_COOLING) return 0;
+    for (int b = 0; b < p->P; b++) {
+        const DevState& st = (*p->h_state)[b];
+        if (st.ref_len > 0 && st.timestep + steps >= st.ref_len)
+            return fail(-5, "reference index out of range: time step " + std::to_string(st.timestep) + " + " +
+                                std::to_string(steps) + " steps, reference of " + std::to_string(st.ref_len) + " rows");
+    }
+    return 0;
+}
 
 extern "C" void mppi_planner_destroy(mppi_planner* p);
 
@@ -354,6 +391,9 @@ static int planner_allocate(mppi_planner* p) {
     HIP_OK(hipMemset(p->d_log_count, 0, 4 * P));
     HIP_OK(hipMalloc(&p->d_next_step, 4 * P));
     HIP_OK(hipMemset(p->d_next_step, 0, 4 * P));
+    HIP_OK(hipMalloc(&p->d_last_row, P * (p->nq + 2 * p->nv + 7) * 8));
+    HIP_OK(hipMemset(p->d_last_row, 0, P * (p->nq + 2 * p->nv + 7) * 8));
+    HIP_OK(hipHostMalloc(&p->h_step, (P * (p->nq + 2 * p->nv + 7) + HM) * 8, hipHostMallocDefault));
     if (cfg->dump) {
         HIP_OK(hipMalloc(&p->d_obs, K * cfg->H * OD * p->esz));
         HIP_OK(hipMalloc(&p->d_rew, K * cfg->H * p->esz));
@@ -384,6 +424,7 @@ int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) try {
         m->ops = &o;
         m->desc = *desc;
         for (auto& x : m->d_io) x = nullptr;
+        for (auto& x : m->io_stream) x = nullptr;
         *out = m;
         return 0;
     }
@@ -395,7 +436,11 @@ int mppi_model_create(const mppi_model_desc* desc, mppi_model** out) try {
 void mppi_model_destroy(mppi_model* m) {
     if (!m) return;
     for (int d = 0; d < 16; d++)
-        if (m->d_io[d]) { (void)hipSetDevice(d); (void)hipFree(m->d_io[d]); }
+        if (m->d_io[d]) {
+            (void)hipSetDevice(d);
+            (void)hipFree(m->d_io[d]);
+            if (m->io_stream[d]) (void)hipStreamDestroy(m->io_stream[d]);
+        }
     delete m;
 }
 
@@ -453,9 +498,10 @@ void mppi_planner_destroy(mppi_planner* p) {
     }
     if (p->d_gathered) (void)hipFree(p->d_gathered);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
+    if (p->h_step) (void)hipHostFree(p->h_step);
     if (p->d_weights) (void)hipFree(p->d_weights);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R,
-                    p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step};
+                    p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step, p->d_last_row};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -467,6 +513,15 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
     if (!p || !qpos || !qvel || !target3 || !timestep) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     // alpha / ref_len come from the host mirror; q, v, target, timestep are replaced
+    std::vector<double> tq, tv, tt;
+    int rc = host_view(qpos, (size_t)p->P * p->nq, tq, &qpos);
+    if (!rc) rc = host_view(qvel, (size_t)p->P * p->nv, tv, &qvel);
+    if (!rc) rc = host_view(target3, (size_t)p->P * 3, tt, &target3);
+    if (rc) return rc;
+    std::vector<int32_t> ts(p->P);
+    if (on_device(timestep)) HIP_OK(hipMemcpy(ts.data(), timestep, (size_t)p->P * 4, hipMemcpyDeviceToHost));
+    else std::memcpy(ts.data(), timestep, (size_t)p->P * 4);
+    timestep = ts.data();
     std::vector<DevState>& s = *p->h_state;
     for (int b = 0; b < p->P; b++) {
         for (int i = 0; i < p->nq; i++) s[b].q[i] = qpos[b * p->nq + i];
@@ -485,7 +540,7 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
 int mppi_set_base_actions(mppi_planner* p, const double* act) try {
     if (!p || !act) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
-    HIP_OK(hipMemcpyAsync(p->d_base, act, (size_t)p->HM * p->P * 8, hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipMemcpyAsync(p->d_base, act, (size_t)p->HM * p->P * 8, hipMemcpyDefault, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
     return 0;
 } catch (const std::exception& e) {
@@ -499,14 +554,16 @@ int mppi_set_reference(mppi_planner* p, const double* ref, int32_t T, double alp
     HIP_OK(hipStreamSynchronize(p->stream));      // rollouts in flight may still read the old rows
     const bool had_ref = (*p->h_state)[0].ref_len > 0;
     if (T > p->ref_cap) {
-        if (p->d_ref) HIP_OK(hipFree(p->d_ref));
-        p->d_ref = nullptr; p->ref_cap = 0;
-        HIP_OK(hipMalloc(&p->d_ref, (size_t)T * 3 * 8));
+        // the new buffer first: if it cannot be had, the planner keeps the reference it has
+        double* fresh = nullptr;
+        HIP_OK(hipMalloc(&fresh, (size_t)T * 3 * 8));
+        if (p->d_ref) (void)hipFree(p->d_ref);
+        p->d_ref = fresh;
         p->ref_cap = T;
         p->cfg_gen++;                             // captured launches hold the old address
     }
     if ((T > 0) != had_ref) p->cfg_gen++;         // with and without a reference are different kernel variants
-    if (T > 0) HIP_OK(hipMemcpyAsync(p->d_ref, ref, (size_t)T * 3 * 8, hipMemcpyHostToDevice, p->stream));
+    if (T > 0) HIP_OK(hipMemcpyAsync(p->d_ref, ref, (size_t)T * 3 * 8, hipMemcpyDefault, p->stream));
     // alpha and the length are fields of the device-resident state, which captured launches read at run time
     for (int b = 0; b < p->P; b++) { (*p->h_state)[b].alpha = alpha; (*p->h_state)[b].ref_len = T; }
     hipLaunchKernelGGL(set_reference_fields_kernel, dim3((p->P + 255) / 256), dim3(256), 0, p->stream, p->d_state, p->P, alpha, (int)T);
@@ -568,7 +625,7 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     if (!p->d_raw) HIP_OK(hipMalloc(&p->d_raw, (size_t)p->HM * p->cfg.K * p->P * 8));      // host-upload staging, on first use
-    HIP_OK(hipMemcpyAsync(p->d_raw, raw, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(p->d_raw, raw, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyDefault, s));
     HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 1, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));     // the host buffer may be reused by the caller
     p->explicit_act = 0;
@@ -594,8 +651,11 @@ int mppi_advance(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance");
     HIP_OK(hipSetDevice(p->cfg.device));
+    const int rc = reference_covers(p, 1);
+    if (rc) return rc;
     HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
-                                  p->d_log, MPPI_LOG_CAP, p->d_log_count, pick(p, stream)));
+                                  p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, pick(p, stream)));
+    for (DevState& st : *p->h_state) st.timestep++;
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -605,9 +665,13 @@ int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance_noise");
     HIP_OK(hipSetDevice(p->cfg.device));
+    const int rc = reference_covers(p, 1);
+    if (rc) return rc;
     HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
-                                        p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->cfg.K,
-                                        p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps, pick(p, stream)));
+                                        p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
+                                        p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps,
+                                        pick(p, stream)));
+    for (DevState& st : *p->h_state) st.timestep++;
     p->explicit_act = 0;
     p->noise_ahead = true;
     p->noise_ahead_seed = seed;
@@ -619,8 +683,7 @@ int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) try {
 int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total) try {
     if (!p || !rows || !n_rows || max_rows < 0 || planner < 0 || planner >= p->P) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(p->cfg.device));
-    HIP_OK(hipStreamSynchronize(p->stream));
-    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipStreamSynchronize(p->stream));      // (the planner's own stream: other planners are left alone)
     int count = 0;
     HIP_OK(hipMemcpy(&count, p->d_log_count + planner, 4, hipMemcpyDeviceToHost));
     const int row = p->nq + 2 * p->nv + 7;
@@ -647,7 +710,7 @@ int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     if (!p->d_raw) HIP_OK(hipMalloc(&p->d_raw, (size_t)p->HM * p->cfg.K * p->P * 8));
-    HIP_OK(hipMemcpyAsync(p->d_raw, act, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(p->d_raw, act, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyDefault, s));
     HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 0, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));
     p->explicit_act = 1;
@@ -725,6 +788,10 @@ static int launch_merge(mppi_planner* p, const double* gathered, int nranks, hip
 
 int mppi_rollout(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
+    {
+        const int rc = reference_covers(p, p->cfg.H);
+        if (rc) return rc;
+    }
     HIP_OK(hipSetDevice(p->cfg.device));
     return launch_rollout_only(p, pick(p, stream));
 } catch (const std::exception& e) {
@@ -734,6 +801,10 @@ int mppi_rollout(mppi_planner* p, void* stream) try {
 int mppi_local_partials(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
+    {
+        const int rc = reference_covers(p, p->cfg.H);
+        if (rc) return rc;
+    }
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     int rc = launch_rollout_only(p, s);
@@ -763,15 +834,19 @@ int mppi_merge(mppi_planner* p, const void* gathered, int32_t nranks, void* stre
 static int build_graph(mppi_planner* p) {
     if (p->graph) { HIP_OK(hipGraphExecDestroy(p->graph)); p->graph = nullptr; }
     p->graph_gen = 0;
-    hipGraph_t g;
     HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
     int rc = launch_rollout_only(p, p->stream);
     if (!rc) rc = launch_update(p, p->stream);
+    hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(p->stream, &g);
-    if (rc) return rc;
+    if (rc) {
+        if (e == hipSuccess && g) (void)hipGraphDestroy(g);
+        return rc;
+    }
     HIP_OK(e);
-    HIP_OK(hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0));
-    HIP_OK(hipGraphDestroy(g));
+    e = hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIP_OK(e);
     p->graph_gen = p->cfg_gen;
     return 0;
 }
@@ -779,6 +854,10 @@ static int build_graph(mppi_planner* p) {
 int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) try {
     if (!p || niter < 0) return fail(-1, "bad argument");
     if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
+    if (niter > 0) {
+        const int rc = reference_covers(p, p->cfg.H);
+        if (rc) return rc;
+    }
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     static const bool use_graph = [] { const char* e = getenv("MPPI_GRAPH"); return !(e && e[0] == '0'); }();
@@ -812,11 +891,11 @@ static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStrea
     }
     if (plan_draws_ahead(p))
         HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
-                                            p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->cfg.K,
-                                            p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps, s));
+                                            p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
+                                            p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps, s));
     else
         HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act,
-                                      p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, s));
+                                      p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, s));
     return 0;
 }
 static int enqueue_plan_noise(mppi_planner* p, uint64_t seed, hipStream_t s) {
@@ -829,6 +908,10 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
     if (!p || niter < 1 || nsteps < 0) return fail(-1, "bad argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_plan");
     if (nsteps == 0) return 0;
+    {   // the last of the steps rolls out from time step t + nsteps - 1
+        const int rc = reference_covers(p, nsteps - 1 + p->cfg.H);
+        if (rc) return rc;
+    }
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     p->explicit_act = 0;
@@ -846,15 +929,19 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
         if (!p->step_graph || p->step_graph_gen != p->cfg_gen || p->step_graph_niter != niter || p->step_graph_seed != seed) {
             if (p->step_graph) { HIP_OK(hipGraphExecDestroy(p->step_graph)); p->step_graph = nullptr; }
             p->step_graph_gen = 0;
-            hipGraph_t g;
+            hipGraph_t g = nullptr;
             HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
             int rc = ahead ? 0 : enqueue_plan_noise(p, seed, p->stream);
             if (!rc) rc = enqueue_plan_body(p, seed, niter, p->stream);
-            const hipError_t e = hipStreamEndCapture(p->stream, &g);
-            if (rc) return rc;
+            hipError_t e = hipStreamEndCapture(p->stream, &g);
+            if (rc) {
+                if (e == hipSuccess && g) (void)hipGraphDestroy(g);
+                return rc;
+            }
             HIP_OK(e);
-            HIP_OK(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
-            HIP_OK(hipGraphDestroy(g));
+            e = hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            HIP_OK(e);
             p->step_graph_gen = p->cfg_gen;
             p->step_graph_niter = niter;
             p->step_graph_seed = seed;
@@ -864,6 +951,22 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
     }
     p->noise_ahead = ahead;
     p->noise_ahead_seed = seed;
+    for (DevState& st : *p->h_state) st.timestep += nsteps;
+    return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
+}
+
+int mppi_read_step(mppi_planner* p, double* rows, double* act_seq) try {
+    if (!p || (!rows && !act_seq)) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    const size_t nrow = (size_t)p->P * (p->nq + 2 * p->nv + 7), nseq = (size_t)p->HM * p->P;
+    // two small copies into page-locked memory behind whatever the planner's stream still holds, one wait
+    if (rows) HIP_OK(hipMemcpyAsync(p->h_step, p->d_last_row, nrow * 8, hipMemcpyDeviceToHost, p->stream));
+    if (act_seq) HIP_OK(hipMemcpyAsync(p->h_step + nrow, p->d_base, nseq * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    if (rows) std::memcpy(rows, p->h_step, nrow * 8);
+    if (act_seq) std::memcpy(act_seq, p->h_step + nrow, nseq * 8);
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -874,7 +977,7 @@ int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     if (override_seq) {
-        HIP_OK(hipMemcpyAsync(p->d_base, override_seq, (size_t)p->HM * p->P * 8, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(p->d_base, override_seq, (size_t)p->HM * p->P * 8, hipMemcpyDefault, s));
         HIP_OK(hipStreamSynchronize(s));
     }
     hipLaunchKernelGGL(shift_kernel, dim3((p->HM + 255) / 256, p->P), dim3(256), 0, s, p->d_base, p->cfg.H, p->nv, p->cfg.default_act,
@@ -1025,12 +1128,14 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) try {
     return fail(-8, std::string("host exception: ") + e.what());
 }
 
-static int env_io(const mppi_model* m, int device, double** io) {
-    if (device < 0 || device >= 16) return fail(-1, "device ordinal out of range");
+// scratch and stream of the single-step entry points on one device; the caller holds m->mu[device]
+static int env_io(const mppi_model* m, int device, double** io, hipStream_t* stream) {
     HIP_OK(hipSetDevice(device));
     mppi_model* mm = const_cast<mppi_model*>(m);
+    if (!mm->io_stream[device]) HIP_OK(hipStreamCreateWithFlags(&mm->io_stream[device], hipStreamNonBlocking));
     if (!mm->d_io[device]) HIP_OK(hipMalloc(&mm->d_io[device], 512 * 8));
     *io = mm->d_io[device];
+    *stream = mm->io_stream[device];
     return 0;
 }
 
@@ -1041,8 +1146,11 @@ int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const
     if ((reward_type == MPPI_REWARD_TRACKING || reward_type == MPPI_REWARD_COOLING) && (!ref || T < 1))
         return fail(-1, "tracking / cooling reward needs a reference");
     const int nv = m->ops->nv, nq = m->ops->nq, ns = nq + nv;
+    if (device < 0 || device >= 16) return fail(-1, "device ordinal out of range");
+    std::lock_guard<std::mutex> turn(const_cast<mppi_model*>(m)->mu[device]);
     double* io;
-    int rc = env_io(m, device, &io);
+    hipStream_t st;
+    int rc = env_io(m, device, &io, &st);
     if (rc) return rc;
     double in[4 * MPPI_MAXV + 16];
     for (int i = 0; i < nq; i++) in[i] = qpos[i];
@@ -1055,10 +1163,11 @@ int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const
         for (int c = 0; c < 3; c++) in[ns + nv + 4 + c] = ref[3 * (timestep + 1) + c];
     }
     const int n_in = ns + nv + 7, n_out = 2 * ns + 7;
-    HIP_OK(hipMemcpy(io, in, n_in * 8, hipMemcpyHostToDevice));
-    HIP_OK(m->ops->env_step(io, reward_type, has_ref, 0, io + 256, 0));
+    HIP_OK(hipMemcpyAsync(io, in, n_in * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(m->ops->env_step(io, reward_type, has_ref, 0, io + 256, st));
     double out[4 * MPPI_MAXV + 16];
-    HIP_OK(hipMemcpy(out, io + 256, n_out * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(out, io + 256, n_out * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
     if (qpos_out) for (int i = 0; i < nq; i++) qpos_out[i] = out[i];
     if (qvel_out) for (int i = 0; i < nv; i++) qvel_out[i] = out[nq + i];
     if (obs_out) for (int i = 0; i < ns + 6; i++) obs_out[i] = out[ns + i];
@@ -1071,15 +1180,19 @@ int mppi_env_step(const mppi_model* m, int32_t device, const double* qpos, const
 int mppi_env_forward(const mppi_model* m, int32_t device, const double* qpos, double* hand3_out) try {
     if (!m || !qpos || !hand3_out) return fail(-1, "null argument");
     const int nv = m->ops->nv, nq = m->ops->nq, ns = nq + nv;
+    if (device < 0 || device >= 16) return fail(-1, "device ordinal out of range");
+    std::lock_guard<std::mutex> turn(const_cast<mppi_model*>(m)->mu[device]);
     double* io;
-    int rc = env_io(m, device, &io);
+    hipStream_t st;
+    int rc = env_io(m, device, &io, &st);
     if (rc) return rc;
     double in[4 * MPPI_MAXV + 16] = {0};
     for (int i = 0; i < nq; i++) in[i] = qpos[i];
-    HIP_OK(hipMemcpy(io, in, (ns + nv + 7) * 8, hipMemcpyHostToDevice));
-    HIP_OK(m->ops->env_step(io, 0, 0, 1, io + 256, 0));
+    HIP_OK(hipMemcpyAsync(io, in, (ns + nv + 7) * 8, hipMemcpyHostToDevice, st));
+    HIP_OK(m->ops->env_step(io, 0, 0, 1, io + 256, st));
     double out[4 * MPPI_MAXV + 16];
-    HIP_OK(hipMemcpy(out, io + 256, (2 * ns + 7) * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(out, io + 256, (2 * ns + 7) * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
     for (int c = 0; c < 3; c++) hand3_out[c] = out[2 * ns + c];
     return 0;
 } catch (const std::exception& e) {
@@ -1116,14 +1229,26 @@ int mppi_comm_init(mppi_planner* p, const void* id, size_t bytes, int32_t rank, 
         (void)api->CommDestroy(comm);
         return fail(-2, std::string("hipMalloc of the gathered rows: ") + hipGetErrorString(e));
     }
-    HIP_OK(hipMemset(p->d_gathered, 0, row * nranks * 8));
+    // from here on a failure leaves the planner as it was: single-rank, its own statistics buffer
+    auto undo = [&]() {
+        (void)api->CommDestroy(comm);
+        (void)hipFree(p->d_gathered);
+        p->d_gathered = nullptr;
+        if (p->d_part_alloc) { p->d_part = p->d_part_alloc; p->d_part_alloc = nullptr; }
+        p->comm = nullptr; p->comm_rank = 0; p->comm_nranks = 0;
+        p->cfg_gen++;
+    };
+    hipError_t he = hipMemset(p->d_gathered, 0, row * nranks * 8);
+    if (he != hipSuccess) { undo(); return fail(-2, std::string("hipMemset of the gathered rows: ") + hipGetErrorString(he)); }
     p->d_part_alloc = p->d_part;
     p->d_part = p->d_gathered + row * rank;       // the statistics kernel writes where the gather expects them
     p->comm = comm; p->comm_rank = rank; p->comm_nranks = nranks;
     // One gather outside any capture: RCCL sets up its connections and buffers at the first collective of a
     // communicator, which must not happen while a stream is being captured.
-    RCCL_OK(api, api->AllGather(p->d_part, p->d_gathered, row, RCCL_FLOAT64, p->comm, p->stream));
-    HIP_OK(hipStreamSynchronize(p->stream));
+    const int ar = api->AllGather(p->d_part, p->d_gathered, row, RCCL_FLOAT64, comm, p->stream);
+    if (ar != 0) { undo(); return fail(-7, std::string("ncclAllGather (first exchange): ") + api->GetErrorString(ar)); }
+    he = hipStreamSynchronize(p->stream);
+    if (he != hipSuccess) { undo(); return fail(-2, std::string("first exchange: ") + hipGetErrorString(he)); }
     p->cfg_gen++;                   // captured updates were the single-rank kind
     return 0;
 } catch (const std::exception& e) {

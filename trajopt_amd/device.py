@@ -205,6 +205,15 @@ class DevicePlanner:
         return dict(qpos=r[:, :nq], qvel=r[:, nq:s], hand=r[:, s:s + 3], target=r[:, s + 3:s + 6],
                     reward=r[:, s + 6], action=r[:, s + 7:], total=total.value)
 
+    def read_step(self):
+        """What the last device-resident advance produced: (rows, act_sequence) -- the newest log row of every planner
+        (qpos', qvel', hand, target, reward, action: (3M+7,), leading P for batches) and the shifted act_sequence."""
+        nv, nq = self.nv, self.nq
+        rows = np.empty(self._lead(nq + 2 * nv + 7))
+        seq = np.empty(self._lead(self.H, nv))
+        L.check(L.lib().mppi_read_step(self._h, L.ptr(rows), L.ptr(seq)))
+        return rows, seq
+
     def upload_actions(self, act):
         act = L.f64(act)
         assert act.shape == self._lead(self.K, self.H, self.nv), act.shape

@@ -157,6 +157,20 @@ class Reacher7DOFEnv:
     def step(self, a):
         return self._step(a)
 
+    def _adopt_step(self, state, action, hand):
+        """Take over the outcome of a `step(action)` that a device-resident planner made from `state` with this
+        environment's own reward: what `set_env_state(state); step(action)` leaves behind, without a launch."""
+        self.sim.reset()
+        self.model.site_pos[self.target_sid] = state['target_pos']
+        self.env_timestep = state['timestep']
+        self.data.qpos[:] = state['qp']
+        self.data.qvel[:] = state['qv']
+        self.data.ctrl[:] = action
+        self.data._refresh = None
+        self.data._site_xpos[self.hand_sid] = hand
+        self.data._site_xpos[self.target_sid] = self.model.site_pos[self.target_sid]
+        self.goal_dist = np.array([np.linalg.norm(self.data._site_xpos[self.hand_sid] - self.data._site_xpos[self.target_sid])])
+
     def _dense_step(self, a):
         """One step with the dense reward whatever `reward_type` says; goal_dist is left untouched."""
         reward = self._advance(np.asarray(a, dtype=np.float64), 'dense')

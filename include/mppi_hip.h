@@ -171,6 +171,15 @@ int mppi_upload_noise(mppi_planner* p, const double* raw_KxHxM, void* stream);
  * mppi_upload_noise / mppi_upload_actions, which copy from it at the bus rate instead of the pageable-memory rate.
  * The uploads return after the copy, so the buffer may be rewritten as soon as they have returned. */
 int mppi_host_staging(mppi_planner* p, double** buffer_out);
+/* The host draws of all workers of `gather_paths_parallel` made and uploaded in one call, the upload running while
+ * the generator works: worker i (trajopt/utils.py:151-152: seed base_seed + i * paths_per_cpu -> seeds[i]) fills
+ * samples [i*K/nstreams, (i+1)*K/nstreams) of the staging buffer (mppi_host_staging) with numpy's legacy stream, and
+ * every finished stretch goes to the device on a side stream.  The planner's own stream is left alone, so the call may
+ * overlap the rollouts of the previous planning step; mppi_commit_noise then applies sigma and the filter on the
+ * planner's stream (behind the upload) and makes the draws the noise of the next rollouts.  state_out as for
+ * mppi_numpy_normals (one stream only), or NULL.  Single planners (P = 1). */
+int mppi_draw_noise(mppi_planner* p, const uint32_t* seeds, int32_t nstreams, int32_t nthreads, uint32_t* state_out);
+int mppi_commit_noise(mppi_planner* p, void* stream);
 int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream);
 /* Same, with the stream key = seed + the planner's current timestep read on the device: the
  * reference re-seeds every planning step with `self.seed + t` (trajopt/algos/mppi.py:130-132). */
@@ -277,6 +286,10 @@ int mppi_numpy_normals(uint32_t seed, size_t n, double* out, int32_t nthreads, u
 /* The streams of several pool workers side by side (trajopt/utils.py:151-163: worker i re-seeds its own generator with
  * seeds[i]): n_each values per stream into out + i * n_each, the threads shared between the streams. */
 int mppi_numpy_normals_many(const uint32_t* seeds, int32_t nstreams, size_t n_each, double* out, int32_t nthreads);
+
+/* Test hook of the host generator: scales the surplus of rejection-sampling attempts its first round makes (1: normal;
+ * negative: the first round falls short and the stream is made again with a larger surplus). */
+void mppi_numpy_normals_test_margin(double scale);
 
 /* Philox-4x32-10 block function (host), for known-answer tests of the device generator. */
 void mppi_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

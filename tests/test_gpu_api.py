@@ -585,3 +585,91 @@ def test_stored_agent_loads_without_unpickling_and_replays(tmp_path):
     a2, b2 = stored, agent
     a2.train_step(niter=2); b2.train_step(niter=2)
     assert np.array_equal(a2.act_sequence, b2.act_sequence) and np.array_equal(a2.sol_state[-1]['qp'], b2.sol_state[-1]['qp'])
+
+
+def test_inputs_may_be_device_memory(oracle_sim):
+    """Noise, actions, base actions, start state and reference handed over as addresses of torch tensors on the GPU
+    (`tensor.data_ptr()`) give what the same values give as numpy arrays."""
+    import ctypes as C
+    import torch
+    from trajopt_amd import _lib as L
+    from trajopt_amd.device import DeviceModel, DevicePlanner
+    lib = L.lib()
+    K, H = 192, 9
+    rs = np.random.RandomState(3)
+    raw, base = rs.randn(K, H, 7), 0.1 * rs.randn(H, 7)
+    q0, v0, tgt = 0.3 * rs.randn(7), rs.randn(7), np.array([0.1, -0.1, 0.05])
+    ref = 0.3 * rs.randn(H + 4, 3)
+    res = []
+    for on_device in (False, True):
+        p = DevicePlanner(DeviceModel.get("reacher_7dof"), K, H, kappa=25.0, sigma=FILTER[0], betas=FILTER[1:],
+                          default_act="mean", reward_type="tracking", dtype="f64")
+        p.set_params(25.0, 0.97, "tracking")
+        if on_device:
+            dev = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+            t_raw, t_base, t_q, t_v, t_t, t_ref = dev(raw), dev(base), dev(q0), dev(v0), dev(tgt), dev(ref)
+            t_ts = dev(np.array([2]), torch.int32)
+            vp = lambda t: C.c_void_p(t.data_ptr())
+            L.check(lib.mppi_set_start_state(p._h, vp(t_q), vp(t_v), vp(t_t), vp(t_ts)))
+            L.check(lib.mppi_set_reference(p._h, vp(t_ref), len(ref), 1.0))
+            L.check(lib.mppi_set_base_actions(p._h, vp(t_base)))
+            L.check(lib.mppi_upload_noise(p._h, vp(t_raw), None))
+        else:
+            p.set_start_state(q0, v0, tgt, 2)
+            p.set_reference(ref, 1.0)
+            p.set_base_actions(base)
+            p.upload_noise(raw)
+        p.iterate(2)
+        out = [p.returns(), p.act_sequence()]
+        acts = base + ref_mppi.filter_noise(raw.copy(), FILTER)
+        if on_device:
+            t_act = dev(acts)
+            L.check(lib.mppi_upload_actions(p._h, vp(t_act), None))
+        else:
+            p.upload_actions(acts)
+        p.rollout()
+        out.append(p.returns())
+        if on_device:
+            L.check(lib.mppi_shift(p._h, vp(t_base), None))
+        else:
+            p.shift(base)
+        out.append(p.act_sequence())
+        res.append(out)
+        p.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    R_o = oracle_sim.rollout(q0, v0, tgt, 2, acts, "tracking", ref, 1.0, gamma=0.97)
+    assert np.abs(res[1][2] - R_o).max() < 1e-8
+
+
+def test_environments_step_from_several_threads(oracle_sim):
+    """Environments of one process share the compiled model handle; two host threads stepping an environment each
+    (ctypes releases the interpreter lock during the call) take turns inside the library and get their own results."""
+    import threading
+    from trajopt.envs.utils import get_environment
+    n = 1000
+    rs = np.random.RandomState(8)
+    acts = rs.randn(2, n, 7)
+    goals = [np.array([0.05, 0.0, 0.1]), np.array([-0.05, 0.1, 0.0])]
+    envs = [get_environment('reacher_7dof') for _ in range(2)]
+    logs = [[], []]
+
+    def run(i):
+        e = envs[i]
+        e.reset_model(goal=goals[i])
+        for t in range(n):
+            ob, r, _, _ = e.step(acts[i, t])
+            logs[i].append((ob.copy(), r))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for i in range(2):
+        q, v = np.zeros(7), np.zeros(7)
+        for t in range(n):
+            # every step from the state the environment itself was in (a thousand free-running steps drift apart)
+            _, _, obs, r, _ = oracle_sim.env_step(q, v, goals[i], acts[i, t], t)
+            assert np.abs(logs[i][t][0] - obs).max() < 1e-9 and abs(logs[i][t][1] - r) < 1e-9, (i, t)
+            q, v = logs[i][t][0][:7], logs[i][t][0][7:14]

@@ -118,7 +118,10 @@ def test_size_independent_properties(dm):
     R0 = p.returns()
     p.set_params(0.0, 1.0, "sparse")
     p.rollout()
-    assert set(np.unique(p.returns() / H)).issubset({-10.0, -100.0, 100.0}) or np.all(p.returns() <= 100.0 * H)
+    # sparse reward, gamma = 1: every return is a sum of H rewards out of {100, -10, -100}
+    levels = {100.0 * a - 10.0 * b - 100.0 * (H - a - b) for a in range(H + 1) for b in range(H + 1 - a)}
+    Rs = p.returns()
+    assert set(np.unique(Rs)).issubset(levels) and len(np.unique(Rs)) > 1
     assert np.all(R0 < 0) and R0.std() > 0
     p.close(); s.close()
 

@@ -171,3 +171,100 @@ def test_end_of_the_reference_raises_like_the_reference(dm):
     e.env_timestep = len(ref) - 1            # the real env: reference[env_timestep + 1]
     with pytest.raises(IndexError):
         e.step(np.zeros(7))
+
+
+def test_end_of_the_reference_through_the_c_abi(dm):
+    """No Python wrapper in between: the library itself answers -5 when a rollout, an iteration, an advance or a
+    captured planning step would index the reference trajectory past its end, from its own copy of the time step
+    (kept in step with device-resident advances); a time step that ran off the end on the device (several planning
+    steps enqueued by one mppi_plan call are checked as a whole before any of them runs) can therefore not happen
+    silently.  The status bit MPPI_STATUS_REF_END is the device's own report of the same event."""
+    import ctypes as C
+    from trajopt_amd import _lib as L
+    from trajopt_amd.device import DevicePlanner
+    lib = L.lib()
+    H, T = 6, 12
+    ref = np.zeros((T, 3)) + np.array([0.6, -0.4, 0.1])
+    p = DevicePlanner(dm, 64, H, kappa=25.0, sigma=FILTER[0], betas=FILTER[1:], default_act="mean", reward_type="tracking",
+                      dtype="f64")
+    p.set_params(25.0, 1.0, "tracking")
+    p.set_reference(ref, 1.0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), 0)
+    # time steps 0 .. 5 can be planned: the last index used is 5 + 6 = 11
+    assert lib.mppi_plan(p._h, 3, 1, 6, None) == 0
+    p.synchronize()
+    assert p.status() & 4 == 0
+    assert p.read_log(16)["total"] == 6
+    # time step 6: index 12 of 12 rows, from every entry point that rolls out
+    for call in (lambda: lib.mppi_plan(p._h, 3, 1, 1, None), lambda: lib.mppi_rollout(p._h, None),
+                 lambda: lib.mppi_iterate(p._h, 1, None), lambda: lib.mppi_local_partials(p._h, None)):
+        assert call() == -5 and b"reference index out of range" in lib.mppi_last_error()
+    # the real environment alone can still step while reference[timestep + 1] exists: 7 .. 11
+    for _ in range(5):
+        assert lib.mppi_advance(p._h, None) == 0
+    assert lib.mppi_advance(p._h, None) == -5
+    assert lib.mppi_advance_noise(p._h, 3, None) == -5
+    p.synchronize()
+    assert p.status() & 4 == 0 and p.read_log(16)["total"] == 11
+    # a caller that moves the time step behind the library's back (a state set on another handle's behalf would be
+    # the library's own; this writes the device copy directly) is caught by the kernels: status bit, last row used
+    q = p.read_log(1)["qpos"][0]
+    p.set_start_state(q, np.zeros(7), np.zeros(3), T - H)          # host and device agree: refused up front
+    assert lib.mppi_rollout(p._h, None) == -5
+    p.set_start_state(q, np.zeros(7), np.zeros(3), T - H - 1)
+    assert lib.mppi_plan(p._h, 3, 1, 2, None) == -5                  # the second of the two steps would run off the end
+    assert lib.mppi_plan(p._h, 3, 1, 1, None) == 0
+    p.synchronize()
+    assert p.status() & 4 == 0
+    p.close()
+
+
+def test_device_reports_the_end_of_the_reference(oracle_sim):
+    """The kernels' own report of the same event.  The library's host-side check is switched off by its test hook
+    (in a child process: the hook is read once), a rollout and an advance then index past the end of the reference:
+    both finish, the status word carries MPPI_STATUS_REF_END, and the rewards are those of the last row."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+from trajopt_amd.device import DeviceModel, DevicePlanner
+H, T = 4, 9
+ref = np.cumsum(np.ones((T, 3)) * 0.01, axis=0)
+p = DevicePlanner(DeviceModel.get("reacher_7dof"), 64, H, kappa=25.0, sigma=np.ones(7), betas=(0.25, 0.8, 0.0),
+                  default_act="mean", reward_type="tracking", dtype="f64", dump=True)
+p.set_params(25.0, 1.0, "tracking")
+p.set_reference(ref, 1.0)
+p.set_base_actions(np.zeros((H, 7)))
+p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - H - 1)
+p.generate_noise(1)
+p.rollout()
+assert p.status() & 4 == 0, "a rollout that fits must not set the bit"
+p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - H + 1)        # indices 7, 8, 9, 10 of 9 rows
+p.rollout()
+assert p.status() & 4 == 4, p.status()
+np.save(sys.argv[1], np.concatenate([p.actions().ravel(), p.rewards().ravel()]))
+q = DevicePlanner(DeviceModel.get("reacher_7dof"), 8, H, default_act="mean", reward_type="tracking", dtype="f64")
+q.set_params(1.0, 1.0, "tracking")
+q.set_reference(ref, 1.0)
+q.set_base_actions(np.zeros((H, 7)))
+q.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - 1)            # the real env would read row 9
+q.advance()
+q.synchronize()
+assert q.status() & 4 == 4, q.status()
+"""
+    import os
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r.npy")
+        env = dict(os.environ, MPPI_NO_HOST_REF_CHECK="1")
+        subprocess.run([sys.executable, "-c", code % root, out], check=True, env=env, timeout=110)
+        got = np.load(out)
+    H, T, K = 4, 9, 64
+    acts, rew = got[:K * H * 7].reshape(K, H, 7), got[K * H * 7:].reshape(K, H)
+    ref = np.cumsum(np.ones((T, 3)) * 0.01, axis=0)
+    padded = np.concatenate([ref, np.repeat(ref[-1:], 4, axis=0)])
+    _, _, rew_o = oracle_sim.rollout(np.zeros(7), np.zeros(7), np.zeros(3), T - H + 1, acts, "tracking", padded, 1.0, dump=True)
+    assert np.abs(rew - rew_o).max() < 1e-9

@@ -71,3 +71,22 @@ def test_several_worker_streams_side_by_side(streams, n_each, threads):
     assert L.lib().mppi_numpy_normals_many(L.ptr(seeds), streams, n_each, L.ptr(out), threads) == 0
     for i in range(streams):
         assert np.array_equal(out[i * n_each:(i + 1) * n_each], np.random.RandomState(int(seeds[i])).normal(size=n_each)), i
+
+
+@pytest.mark.parametrize("seed,n,threads", [(21, 100001, 8), (8, 64, 1), (13, 300000, 2)])
+def test_a_round_of_attempts_that_falls_short_is_made_again_exactly(seed, n, threads):
+    """The rejection sampler makes its attempts in bulk with a surplus; if a round still ends short of the values
+    asked for, the stream is made again from the seed with a larger surplus.  The test hook removes the surplus of
+    the first round, which forces that path: stream and generator state must be numpy's all the same."""
+    from trajopt_amd import _lib as L
+    L.lib().mppi_numpy_normals_test_margin(-1.0)
+    try:
+        got, state = _ours(seed, n, threads)
+    finally:
+        L.lib().mppi_numpy_normals_test_margin(1.0)
+    np.random.seed(seed)
+    want = np.random.normal(loc=0, scale=1.0, size=n)
+    assert np.array_equal(got, want)
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    assert np.array_equal(state[:624], key) and int(state[624]) == pos and int(state[625]) == has_gauss
+    assert state[626:628].view(np.float64)[0] == cached

@@ -64,6 +64,8 @@ _PROTOS = {
     "mppi_set_critic": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, C.c_float]),
     "mppi_upload_noise": (C.c_int, [_vp, _vp, _vp]),
     "mppi_host_staging": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "mppi_draw_noise": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "mppi_commit_noise": (C.c_int, [_vp, _vp]),
     "mppi_generate_noise": (C.c_int, [_vp, _u64, _vp]),
     "mppi_generate_noise_step": (C.c_int, [_vp, _u64, _vp]),
     "mppi_advance": (C.c_int, [_vp, _vp]),
@@ -90,6 +92,7 @@ _PROTOS = {
     "mppi_update_from_returns_noalloc": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _d, _vp, _vp]),
     "mppi_numpy_normals": (C.c_int, [C.c_uint32, C.c_size_t, _vp, _i32, _vp]),
     "mppi_numpy_normals_many": (C.c_int, [_vp, _i32, C.c_size_t, _vp, _i32]),
+    "mppi_numpy_normals_test_margin": (None, [_d]),
     "mppi_philox4x32": (None, [_vp, _vp, _vp]),
 }
 EXPORTS = tuple(_PROTOS)

@@ -21,8 +21,8 @@ Two keyword arguments are additions with behaviour-preserving defaults:
 import numpy as np
 
 from ..device import DeviceModel, DevicePlanner, update_from_returns
-from ..utils import (ReplayBuffer, Tuple, _set_numpy_state, all_worker_normals, gather_paths_parallel,  # noqa: F401
-                     rollout_objective, score_trajectory)
+from ..utils import (ReplayBuffer, Tuple, _host_threads, _set_numpy_state, all_worker_normals,  # noqa: F401
+                     gather_paths_parallel, rollout_objective, score_trajectory, worker_seeds)
 from .trajopt_base import Trajectory
 
 _KERNEL_ENVS = {'reacher_7dof': 'reacher_7dof', 'continual_reacher_7dof': 'reacher_7dof'}
@@ -225,26 +225,29 @@ class MPPI(Trajectory):
                 p.generate_noise(seed)
                 p.iterate(niter)
         else:
-            # The host stream of planning step t + 1 depends on nothing but its seed, so it is drawn while the device
-            # works on step t (the staging buffer is free again once the upload has returned).  What was drawn ahead
+            # The host stream of planning step t + 1 depends on nothing but its seed, so it is drawn -- and sent to the
+            # device, piece by piece behind the generator -- while the device works on step t.  What was drawn ahead
             # is used only if the next call asks for exactly that stream from the same planner; the process-global
-            # numpy generator is moved when the draws are consumed, as if they had been made then.
-            buf = p.host_staging()
+            # numpy generator is moved when the draws are consumed, as if they had been made then (one worker runs
+            # in-process in the reference, trajopt/utils.py:171-172, and leaves the global generator behind its draws;
+            # pool workers re-seed only their own copies).
+            def draw(sd):
+                return p.draw_noise(worker_seeds(sd, self.paths_per_cpu, self.num_cpu), _host_threads(),
+                                    want_state=self.num_cpu == 1)
             want = (id(p), seed, self.paths_per_cpu, self.num_cpu, H, self.m)
             if self._ahead is not None and self._ahead[0] == want:
                 state = self._ahead[1]
             else:
-                _, state = all_worker_normals(seed, self.paths_per_cpu, self.num_cpu, H, self.m, out=buf, defer_state=True)
+                state = draw(seed)
             self._ahead = None
             if state is not None:
                 _set_numpy_state(state)
-            p.upload_noise(buf)
+            p.commit_noise()
             p.iterate(niter)
             if advance:
                 p.advance()
-            if self.draw_ahead and 0 <= seed + 1 < 2 ** 32:
-                _, state = all_worker_normals(seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m, out=buf, defer_state=True)
-                self._ahead = ((id(p), seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m), state)
+            if self.draw_ahead and 0 <= seed + 1 + (self.num_cpu - 1) * self.paths_per_cpu < 2 ** 32:
+                self._ahead = ((id(p), seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m), draw(seed + 1))
         if not advance:
             self.act_sequence = p.act_sequence()
             self._dev_seq = (id(p), self.act_sequence.copy())

@@ -23,12 +23,15 @@
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/mppi_hip.h"
+#include "numpy_stream.h"
 #include "env_core.hpp"
 #include "models_gen.hpp"
 
@@ -287,6 +290,10 @@ struct mppi_planner {
     void* d_eps;           // T [H][M][K]
     double* d_raw;         // staging for host uploads [K][H][M]
     double* h_stage;       // page-locked host buffer of the same size, made on request
+    hipStream_t copy_stream;       // uploads that run beside the planner's own work (mppi_draw_noise)
+    hipEvent_t ev_raw_free;        // recorded on the planner's stream behind the last kernel that read d_raw
+    hipEvent_t ev_upload_done;     // recorded on copy_stream behind the last piece of a streamed upload
+    bool raw_pending;              // d_raw holds (or is receiving) draws that mppi_commit_noise has not filtered yet
     double* d_weights;     // [P][K + 2] the update's weights, Rmax, arg-max: large K only (update_wants_weights)
     double* d_ref;
     int ref_cap;
@@ -353,6 +360,9 @@ static int host_view(const double* src, size_t n, std::vector<double>& tmp, cons
 // device-resident advances)
 static int reference_covers(const mppi_planner* p, int steps) {
     if (p->cfg.reward_type != REWARD_TRACKING && p->cfg.reward_type != REWARD_COOLING) return 0;
+    // (test hook: with MPPI_NO_HOST_REF_CHECK=1 the kernels' own report, MPPI_STATUS_REF_END, can be observed)
+    static const bool skip = [] { const char* e = getenv("MPPI_NO_HOST_REF_CHECK"); return e && e[0] == '1'; }();
+    if (skip) return 0;
     for (int b = 0; b < p->P; b++) {
         const DevState& st = (*p->h_state)[b];
         if (st.ref_len > 0 && st.timestep + steps >= st.ref_len)
@@ -499,6 +509,9 @@ void mppi_planner_destroy(mppi_planner* p) {
     if (p->d_gathered) (void)hipFree(p->d_gathered);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
     if (p->h_step) (void)hipHostFree(p->h_step);
+    if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
+    if (p->ev_raw_free) (void)hipEventDestroy(p->ev_raw_free);
+    if (p->ev_upload_done) (void)hipEventDestroy(p->ev_upload_done);
     if (p->d_weights) (void)hipFree(p->d_weights);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R,
                     p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step, p->d_last_row};
@@ -625,9 +638,75 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     if (!p->d_raw) HIP_OK(hipMalloc(&p->d_raw, (size_t)p->HM * p->cfg.K * p->P * 8));      // host-upload staging, on first use
+    if (p->copy_stream) HIP_OK(hipStreamSynchronize(p->copy_stream));      // a streamed upload may still be landing in d_raw
+    p->raw_pending = false;
     HIP_OK(hipMemcpyAsync(p->d_raw, raw, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyDefault, s));
     HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 1, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));     // the host buffer may be reused by the caller
+    p->explicit_act = 0;
+    p->noise_ahead = false;
+    return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
+}
+
+// The draws of `generate_paths` for all workers (trajopt/utils.py:135-139, 151-152), made on the host and sent to the
+// device while they are being made: worker i's stream (np.random.seed(seeds[i])) fills samples [i*K/nstreams,
+// (i+1)*K/nstreams) of the planner's page-locked staging buffer, and every finished stretch of a stream is copied to
+// the device on a side stream at once, so that the copy ends with the generator.  The planner's own stream is not
+// touched: it may be rolling out the previous planning step meanwhile.
+int mppi_draw_noise(mppi_planner* p, const uint32_t* seeds, int32_t nstreams, int32_t nthreads, uint32_t* state_out) try {
+    if (!p || !seeds || nstreams < 1) return fail(-1, "bad argument");
+    if (p->P != 1) return fail(-4, "mppi_draw_noise serves single planners");
+    const size_t total = (size_t)p->HM * p->cfg.K;
+    if (p->cfg.K % nstreams != 0) return fail(-1, "the streams must share the samples evenly");
+    if (state_out && nstreams != 1) return fail(-1, "the generator state is reported for a single stream only");
+    const size_t n_each = total / nstreams;
+    HIP_OK(hipSetDevice(p->cfg.device));
+    if (!p->h_stage) HIP_OK(hipHostMalloc(&p->h_stage, total * 8, hipHostMallocDefault));
+    if (!p->d_raw) HIP_OK(hipMalloc(&p->d_raw, total * 8));
+    if (!p->copy_stream) {
+        HIP_OK(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&p->ev_raw_free, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&p->ev_upload_done, hipEventDisableTiming));
+        HIP_OK(hipEventRecord(p->ev_raw_free, p->stream));
+    }
+    // d_raw is free once the filter kernel of the previous commit has read it
+    HIP_OK(hipStreamWaitEvent(p->copy_stream, p->ev_raw_free, 0));
+    p->raw_pending = true;
+    // every stretch of at least PIECE finished values of a stream (and whatever is left at its end) is sent by the
+    // generator thread that finished it
+    constexpr size_t PIECE = 64 * 1024;                // values: 512 KiB per copy
+    std::vector<size_t> sent(nstreams, 0);
+    std::atomic<int> copy_err{(int)hipSuccess};
+    const std::function<void(int, size_t)> on_ready = [&](int i, size_t have) {
+        if (have - sent[i] < PIECE && have < n_each) return;
+        const size_t at = (size_t)i * n_each + sent[i];
+        const hipError_t e = hipMemcpyAsync(p->d_raw + at, p->h_stage + at, (have - sent[i]) * 8, hipMemcpyHostToDevice, p->copy_stream);
+        if (e != hipSuccess) copy_err.store((int)e);
+        sent[i] = have;
+    };
+    const int rc = mppi_numpy_normals_streams(seeds, nstreams, n_each, p->h_stage, nthreads, state_out, &on_ready);
+    if (copy_err.load() != (int)hipSuccess)
+        return fail(-2, std::string("streamed upload: ") + hipGetErrorString((hipError_t)copy_err.load()));
+    if (rc) return fail(rc, "the host generator failed");
+    HIP_OK(hipEventRecord(p->ev_upload_done, p->copy_stream));
+    return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
+}
+
+// sigma scaling and recursive filter (trajopt/utils.py:121-125) of the draws mppi_draw_noise sent, on the planner's
+// stream behind the last piece of the upload; the next rollouts perturb the base actions with them
+int mppi_commit_noise(mppi_planner* p, void* stream) try {
+    if (!p) return fail(-1, "null argument");
+    if (!p->raw_pending) return fail(-4, "no draws waiting on the device: call mppi_draw_noise first");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    hipStream_t s = pick(p, stream);
+    HIP_OK(hipStreamWaitEvent(s, p->ev_upload_done, 0));
+    HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 1, p->d_eps, s));
+    HIP_OK(hipEventRecord(p->ev_raw_free, s));
+    p->raw_pending = false;
     p->explicit_act = 0;
     p->noise_ahead = false;
     return 0;
@@ -710,6 +789,8 @@ int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     if (!p->d_raw) HIP_OK(hipMalloc(&p->d_raw, (size_t)p->HM * p->cfg.K * p->P * 8));
+    if (p->copy_stream) HIP_OK(hipStreamSynchronize(p->copy_stream));
+    p->raw_pending = false;
     HIP_OK(hipMemcpyAsync(p->d_raw, act, (size_t)p->HM * p->cfg.K * p->P * 8, hipMemcpyDefault, s));
     HIP_OK(p->model->ops->noise_upload(p->cfg.dtype, p->d_raw, p->cfg.K, p->cfg.H, p->P, p->fc, 0, p->d_eps, s));
     HIP_OK(hipStreamSynchronize(s));

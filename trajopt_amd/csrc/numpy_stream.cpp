@@ -12,12 +12,15 @@
 #include <cstdint>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <sched.h>
+#include <system_error>
 #include <thread>
 #include <vector>
 
 #include "../../include/mppi_hip.h"
+#include "numpy_stream.h"
 
 // products and sums must round one by one, as in numpy's generator
 #pragma STDC FP_CONTRACT OFF
@@ -136,38 +139,60 @@ int usable_processors() {
     return n ? (int)n : 1;
 }
 
+// threads that are joined on every way out of the scope that started them
+struct Pool {
+    std::vector<std::thread> threads;
+    ~Pool() { for (auto& t : threads) if (t.joinable()) t.join(); }
+};
+
+// test hook: scales the surplus of attempts the first round makes (1: the normal margin; a negative value makes the
+// first round fall short, so that the restart below runs)
+std::atomic<double> g_margin_scale{1.0};
+
 // One stream: n values after np.random.seed(seed) into out, state_out as described at mppi_numpy_normals.
 // The calling thread runs the recurrence (sequential by nature) chunk by chunk into a ring, every state block made
 // from the one before it where it lies; the other threads follow behind it: a chunk is tempered in place, its
 // attempts are tested and compacted, its slot is handed back, its number of accepted pairs is published, and as soon
 // as the chunks before it have published theirs the chunk knows where its values go in `out` and writes them there.
-void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* state_out, Scratch& S) {
+// ready (may be null) is called with the number of leading values of `out` that are final whenever that number has
+// grown (from whichever thread finished the chunk, one call at a time), for a consumer that takes them away while
+// the rest is still being made.
+void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* state_out, Scratch& S,
+              const std::function<void(size_t)>* ready = nullptr) {
     std::lock_guard<std::mutex> lock(S.mu);
     if (S.ring.size() < RING * SLOT) S.ring.resize(RING * SLOT);
     if (S.local.size() < (size_t)nthreads) S.local.resize(nthreads);
+    for (int t = 0; t < nthreads; t++) S.local[t].reserve();      // every allocation happens here, in the caller
     uint32_t* const ring = S.ring.data();
-    State key;                                        // the generator: state after the last block made
-    seed_state(seed, key);
     const size_t pairs = (n + 1) / 2;                 // accepted attempts needed (the last may give one value only)
-    size_t have = 0;
-    State at_last = key;                              // generator at the start of the chunk that holds the last pair
+    State at_last;                                    // generator at the start of the chunk that holds the last pair
     size_t words_into_last = 0;                       // outputs numpy consumes from there on
     double cached = 0.0;
-    while (have < pairs) {
-        // An attempt takes four generator outputs and is accepted with probability pi / 4.  Attempts are made in
-        // bulk, a little more than the expected number; outputs drawn beyond the last attempt numpy would make are
-        // simply never looked at (the generator object does not outlive the call: every call re-seeds).
-        const size_t attempts = (size_t)((pairs - have) * 1.2733 + 8.0 * std::sqrt((double)(pairs - have))) + 64;
+    size_t reported = 0;                              // (under prefix_mu)
+    // An attempt takes four generator outputs and is accepted with probability pi / 4.  Attempts are made in bulk, a
+    // little more than the expected number; outputs drawn beyond the last attempt numpy would make are simply never
+    // looked at (the generator object does not outlive the call: every call re-seeds).  Should a round end short of
+    // the pairs needed (the margin makes that a 1e-40 event), the stream is made again from the seed with twice the
+    // margin: every round is numpy's stream from its first word, so a round that suffices is exact.
+    for (double margin = 8.0 * g_margin_scale.load();; margin = margin > 0 ? 2.0 * margin : 8.0) {
+        State key;                                    // the generator: state after the last block made
+        seed_state(seed, key);
+        const double surplus = margin * std::sqrt((double)pairs) + (margin > 0 ? 64.0 : 0.0);
+        const double want = pairs * 1.2733 + surplus;
+        const size_t attempts = want > 4.0 ? (size_t)want : 4;
         const size_t nchunks = (attempts + CHUNK - 1) / CHUNK;
         std::vector<State> snapshot(nchunks);
         std::vector<std::atomic<int64_t>> offset(nchunks + 1);
-        std::vector<std::atomic<uint8_t>> released(nchunks);
+        std::vector<std::atomic<uint8_t>> released(nchunks), written(nchunks);
         for (auto& o : offset) o.store(-1, std::memory_order_relaxed);
         for (auto& r : released) r.store(0, std::memory_order_relaxed);
-        offset[0].store((int64_t)have, std::memory_order_release);
+        for (auto& w : written) w.store(0, std::memory_order_relaxed);
+        offset[0].store(0, std::memory_order_release);
         std::atomic<size_t> made{0}, next{0};
         std::atomic<size_t> last_chunk{0}, last_words{0};
         std::atomic<uint64_t> last_cached{0};
+        std::mutex prefix_mu;
+        size_t prefix_chunk = 0;
 
         auto produce = [&](size_t c) {
             const size_t lo = c * CHUNK, hi = lo + CHUNK < attempts ? lo + CHUNK : attempts;
@@ -217,10 +242,23 @@ void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* stat
                     last_words.store(4 * ((size_t)L.att[i] + 1), std::memory_order_relaxed);
                 }
             }
+            written[c].store(1, std::memory_order_release);
+            if (ready) {
+                // leading values that are final: everything before the first chunk still being written
+                std::lock_guard<std::mutex> g(prefix_mu);
+                while (prefix_chunk < nchunks && written[prefix_chunk].load(std::memory_order_acquire)) prefix_chunk++;
+                size_t vals = n;
+                if (prefix_chunk < nchunks) {
+                    const int64_t first_open = offset[prefix_chunk].load(std::memory_order_acquire);     // set: its predecessor wrote
+                    vals = 2 * (size_t)first_open < n ? 2 * (size_t)first_open : n;
+                } else if ((size_t)offset[nchunks].load(std::memory_order_acquire) < pairs) {
+                    vals = 2 * (size_t)offset[nchunks].load(std::memory_order_acquire);                 // a short round
+                }
+                if (vals > reported) { reported = vals; (*ready)(vals); }
+            }
         };
         auto follow = [&](int t) {
             Local& L = S.local[t];
-            L.reserve();
             for (;;) {
                 const size_t c = next.fetch_add(1, std::memory_order_relaxed);
                 if (c >= nchunks) return;
@@ -228,25 +266,33 @@ void generate(uint32_t seed, size_t n, double* out, int nthreads, uint32_t* stat
             }
         };
 
+        bool piped = false;
         if (nthreads > 1 && nchunks >= 4) {
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nthreads; t++) pool.emplace_back(follow, t);
-            for (size_t c = 0; c < nchunks; c++) produce(c);
-            follow(0);
-            for (auto& th : pool) th.join();
-        } else {
-            S.local[0].reserve();
-            for (size_t c = 0; c < nchunks; c++) { produce(c); consume(c, S.local[0]); }
+            Pool pool;
+            try {
+                for (int t = 1; t < nthreads; t++) pool.threads.emplace_back(follow, t);
+            } catch (const std::system_error&) {
+                // fewer followers than asked for: the pipeline works with any number of them, but not with none
+            }
+            if (!pool.threads.empty()) {
+                piped = true;
+                for (size_t c = 0; c < nchunks; c++) produce(c);
+                follow(0);
+            }
         }
+        if (!piped)
+            for (size_t c = 0; c < nchunks; c++) { produce(c); consume(c, S.local[0]); }
         const size_t total = (size_t)offset[nchunks].load(std::memory_order_acquire);
         if (total >= pairs) {
             at_last = snapshot[last_chunk.load()];
             words_into_last = last_words.load();
             const uint64_t bits = last_cached.load();
             std::memcpy(&cached, &bits, 8);
+            break;
         }
-        have = total;
+        // (a short round: what it wrote is the stream's true beginning and is written again, identically)
     }
+    if (ready && reported < n) (*ready)(n);
     if (state_out) {
         // replay from the start of that chunk up to the block of the last output numpy consumes
         const size_t regenerations = (words_into_last + NW - 1) / NW;
@@ -290,14 +336,20 @@ extern "C" int mppi_numpy_normals(uint32_t seed, size_t n, double* out, int32_t 
 
 // The streams of several workers at once: worker i draws n_each values after np.random.seed(seeds[i]) into
 // out + i * n_each (the reference's pool workers, trajopt/utils.py:151-163, each re-seed their own generator).
-// Streams run side by side, sharing the threads between them.
-extern "C" int mppi_numpy_normals_many(const uint32_t* seeds, int32_t nstreams, size_t n_each, double* out,
-                                       int32_t nthreads) try {
+// Streams run side by side, sharing the threads between them.  ready (may be null): called with (stream, number of
+// leading values of that stream that are final) whenever that number has grown; calls for one stream come one at a
+// time, calls for different streams may overlap.  state_out (may be null; one stream only): as for mppi_numpy_normals.
+int mppi_numpy_normals_streams(const uint32_t* seeds, int32_t nstreams, size_t n_each, double* out, int32_t nthreads,
+                               uint32_t* state_out, const std::function<void(int, size_t)>* ready) {
     if (nstreams < 0 || (nstreams && !seeds) || (!out && n_each && nstreams)) return -1;
+    if (state_out && nstreams != 1) return -1;
     nthreads = clamp_threads(nthreads);
     const int lanes = nstreams < nthreads ? nstreams : nthreads;          // streams in flight
     if (lanes <= 1) {
-        for (int i = 0; i < nstreams; i++) generate(seeds[i], n_each, out + (size_t)i * n_each, nthreads, nullptr, g_scratch[0]);
+        for (int i = 0; i < nstreams; i++) {
+            const std::function<void(size_t)> one = [&](size_t have) { (*ready)(i, have); };
+            generate(seeds[i], n_each, out + (size_t)i * n_each, nthreads, state_out, g_scratch[0], ready ? &one : nullptr);
+        }
         return 0;
     }
     const int per = nthreads / lanes > 0 ? nthreads / lanes : 1;
@@ -305,15 +357,30 @@ extern "C" int mppi_numpy_normals_many(const uint32_t* seeds, int32_t nstreams, 
     std::atomic<bool> failed{false};
     auto run = [&](int lane) {
         try {
-            for (int i; (i = next.fetch_add(1)) < nstreams;)
-                generate(seeds[i], n_each, out + (size_t)i * n_each, per, nullptr, g_scratch[lane]);
+            for (int i; (i = next.fetch_add(1)) < nstreams;) {
+                const std::function<void(size_t)> one = [&](size_t have) { (*ready)(i, have); };
+                generate(seeds[i], n_each, out + (size_t)i * n_each, per, nullptr, g_scratch[lane], ready ? &one : nullptr);
+            }
         } catch (const std::exception&) { failed.store(true); }
     };
-    std::vector<std::thread> pool;
-    for (int l = 1; l < lanes; l++) pool.emplace_back(run, l);
-    run(0);
-    for (auto& th : pool) th.join();
+    {
+        Pool pool;
+        try {
+            for (int l = 1; l < lanes; l++) pool.threads.emplace_back(run, l);
+        } catch (const std::system_error&) {
+            // the streams not taken by a started thread are made by this one
+        }
+        run(0);
+    }
     return failed.load() ? -8 : 0;
+}
+
+extern "C" int mppi_numpy_normals_many(const uint32_t* seeds, int32_t nstreams, size_t n_each, double* out,
+                                       int32_t nthreads) try {
+    return mppi_numpy_normals_streams(seeds, nstreams, n_each, out, nthreads, nullptr, nullptr);
 } catch (const std::exception&) {
     return -8;
 }
+
+// test hook (see g_margin_scale)
+extern "C" void mppi_numpy_normals_test_margin(double scale) { g_margin_scale.store(scale); }

@@ -175,6 +175,18 @@ class DevicePlanner:
         assert raw.shape == self._lead(self.K, self.H, self.nv), raw.shape
         L.check(L.lib().mppi_upload_noise(self._h, L.ptr(raw), None))
 
+    def draw_noise(self, seeds, nthreads=16, want_state=False):
+        """numpy's legacy normal stream for every worker seed, made on the host into the staging buffer and sent to the
+        device while it is being made (on a side stream: the planner's own work goes on).  Returns the 628-word
+        generator state record (one seed, want_state) or None.  `commit_noise` makes the draws the planner's noise."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        state = np.empty(628, dtype=np.uint32) if want_state else None
+        L.check(L.lib().mppi_draw_noise(self._h, L.ptr(seeds), len(seeds), int(nthreads), L.ptr(state)))
+        return state
+
+    def commit_noise(self, stream=None):
+        L.check(L.lib().mppi_commit_noise(self._h, stream))
+
     def generate_noise(self, seed, stream=None):
         L.check(L.lib().mppi_generate_noise(self._h, int(seed) & (2 ** 64 - 1), stream))
 

@@ -238,8 +238,20 @@ def _host_threads():
     if _HOST_THREADS is None:
         import os
         n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        _HOST_THREADS = max(1, min(16, n, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+        try:                # OMP_NUM_THREADS may be a list ("4,2": one value per nesting level) or empty
+            omp = int(os.environ.get("OMP_NUM_THREADS", "16").split(",")[0])
+        except ValueError:
+            omp = 16
+        _HOST_THREADS = max(1, min(16, n, omp))
     return _HOST_THREADS
+
+
+def worker_seeds(base_seed, paths_per_cpu, num_cpu):
+    """Seeds of the pool workers, worker i: base_seed + i * paths_per_cpu (trajopt/utils.py:151-152)."""
+    seeds = [int(base_seed) + i * paths_per_cpu for i in range(num_cpu)]
+    if not all(0 <= s < 2 ** 32 for s in seeds):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    return np.array(seeds, dtype=np.uint32)
 
 
 def _set_numpy_state(state):

@@ -10,8 +10,11 @@ device and enqueued on one stream without host synchronisation: Philox noise + f
 K x H rollouts with fused reward / discounted return, max / weights / weighted action sum
 (N > 1: this shard's statistics, one RCCL all-gather of 3 + H*M doubles per rank made by the library,
 rank-ordered merge), the single fp64 step of the real environment from the planner's own state, and
-the horizon shift.  A step is one `mppi_plan` call, the replay of one captured hipGraph (every 8th
-step is launched piece by piece with HIP events around the rollout kernel: roofline.kernel_ms).
+the horizon shift.  A step is one `mppi_plan` call, the replay of one captured hipGraph.  After the
+timed region the same steps are launched piece by piece with HIP events around every rollout
+kernel (roofline.kernel_ms), and -- one GPU only -- the other flavours of the step are timed and
+reported as extra keys: the step with numpy noise uploaded from the host (`host_noise`) and the
+drop-in `MPPI.train_step` through the Python API (`train_step_ms`).
 Sample noise is addressed by global index, so the planner's result does not depend on N.  With N > 1
 rank 0 first times the same K = 65536 planner on its GPU alone; `strong_scaling.efficiency` is
 T(1) / (N * T(N)).
@@ -90,17 +93,46 @@ def flops_per_env_step():
     return total / n
 
 
+def _profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
+
+
 def measured_traffic():
     """HBM bytes per rollout launch from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE
     passes, gfx950 corrections applied); None if the summary is not for this workload."""
-    path = os.path.join(ROOT, "profiles", "r2_rollout_traffic.json")
+    d = _profile("r3_rollout_traffic.json")
     try:
-        d = json.load(open(path))
-        if d.get("K") == K_PER_GPU and d.get("H") == H:
+        if d and d.get("K") == K_PER_GPU and d.get("H") == H:
             return float(d["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
+    except (ValueError, KeyError):
         pass
     return None
+
+
+def issue_statistics(flops_algorithmic):
+    """What limits the rollout kernel at this size, from the committed counter summaries of the same kernel and workload
+    shape (rocprofv3 --pmc over tools/ksweep.py 4096; profiles/r3_rollout_pmc_sq.json, r3_rollout_flops.json):
+    how busy the instruction issue of a wave is, what share of the GPU's vector issue slots the launch uses, and the
+    floating-point operations the kernel executes (it folds the model's structural zeros, which the algorithmic count
+    of the generic algorithm includes)."""
+    out = {}
+    sq = _profile("r3_rollout_pmc_sq.json")
+    if sq and "per_wave_substep" in sq:
+        w = sq["per_wave_substep"]
+        waves, simds = (K_PER_GPU + 63) // 64, 1024
+        out["valu_per_wave_substep"] = w.get("SQ_INSTS_VALU")
+        out["wave_issue_busy_frac"] = w.get("SQ_ACTIVE_INST_ANY", 0.0) / w["SQ_WAVE_CYCLES"]
+        # vector instructions x 4 cycles x waves / (SIMDs x kernel cycles); SQ cycle counters are in quad-cycles
+        out["issue_slot_frac"] = w["SQ_INSTS_VALU"] * waves / (simds * w["SQ_WAVE_CYCLES"])
+        out["waves"], out["simds"] = waves, simds
+    fl = _profile("r3_rollout_flops.json")
+    if fl and "executed_flop_per_env_step" in fl:
+        out["executed_flop_per_env_step"] = fl["executed_flop_per_env_step"]
+        out["executed_over_algorithmic"] = fl["executed_flop_per_env_step"] / flops_algorithmic
+    return out
 
 
 def make_planner(K, k_offset, device):
@@ -112,12 +144,72 @@ def make_planner(K, k_offset, device):
     return p
 
 
+def other_step_flavours(sptr):
+    """The planning step as the reference's configurations word it, timed on one GPU after the headline loop:
+    numpy noise uploaded from the host (exact-comparison mode) through the C ABI, and the drop-in
+    `MPPI.train_step` of the Python API with device noise and with numpy noise."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    from trajopt_amd.utils import _host_threads, worker_seeds
+    n = 40
+    out = {}
+    p = make_planner(K_PER_GPU, 0, int(os.environ.get("LOCAL_RANK", "0")))
+    # (a) the draws are there (page-locked staging buffer): upload + filter, rollouts, update, real-env step
+    p.draw_noise(worker_seeds(SEED, K_PER_GPU, 1), _host_threads())
+    p.commit_noise()
+    stage = p.host_staging()
+    for timed in (False, True):
+        t0 = time.perf_counter()
+        for _ in range(n if timed else 3):
+            p.upload_noise(stage)
+            p.iterate(1, sptr)
+            p.advance(sptr)
+        p.synchronize()
+        up_ms = 1e3 * (time.perf_counter() - t0) / n
+    # (b) the draws are made for every step (numpy's legacy stream, bit for bit) and sent while they are made;
+    #     the stream of step t + 1 is drawn while the device works on step t, as `train_step` does
+    p.draw_noise(worker_seeds(SEED, K_PER_GPU, 1), _host_threads())
+    for timed in (False, True):
+        t0 = time.perf_counter()
+        for i in range(n if timed else 3):
+            p.commit_noise()
+            p.iterate(1)
+            p.advance()
+            p.draw_noise(worker_seeds(SEED + 1 + i, K_PER_GPU, 1), _host_threads())
+            p.read_step()
+        gen_ms = 1e3 * (time.perf_counter() - t0) / n
+    p.close()
+    out["host_noise"] = {"ms_per_step_noise_uploaded": up_ms, "env_steps_per_sec_noise_uploaded": K_PER_GPU * H / (up_ms * 1e-3),
+                         "ms_per_step_noise_drawn_and_uploaded": gen_ms, "host_threads": _host_threads(),
+                         "what": "K=%d, H=%d: 14.7 MB of fp64 draws per step from the page-locked staging buffer "
+                                 "(mppi_upload_noise: copy + sigma / filter kernel), mppi_iterate, mppi_advance; second figure: "
+                                 "numpy's legacy stream generated per step and streamed to the device while it is made "
+                                 "(mppi_draw_noise / mppi_commit_noise), state read back every step" % (K_PER_GPU, H)}
+    ts = {}
+    for noise in ("philox", "host"):
+        e = get_environment('reacher_7dof')
+        e.reset_model(seed=3, goal=(0, 0, 0))
+        ag = MPPI(e, H=H, paths_per_cpu=K_PER_GPU, num_cpu=1, kappa=KAPPA, gamma=GAMMA, mean=np.zeros(M), filter_coefs=FILTER,
+                  default_act='mean', seed=SEED, noise=noise)
+        for _ in range(3):
+            ag.train_step(niter=1)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ag.train_step(niter=1)
+        ts[noise] = 1e3 * (time.perf_counter() - t0) / n
+        ag._planner.close()
+    out["train_step_ms"] = dict(ts, what="MPPI.train_step(niter=1) of the Python API, K=%d, H=%d: whole call, logs and "
+                                         "real-env step included" % (K_PER_GPU, H))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-noise and train_step timings (one GPU)")
     args = ap.parse_args()
 
     # RCCL prints a version banner on standard output when a communicator is made; the result line must be the only
@@ -210,14 +302,13 @@ def main():
 
     # Every step is one mppi_plan call: noise (drawn ahead in the previous step's advance launch), rollouts, update
     # (sharded: statistics, all-gather, merge), real-env fp64 step, horizon shift -- a replay of one captured
-    # hipGraph.  On every PROFILE_EVERY-th step the same work is launched piece by piece instead, with HIP events
-    # around the rollout kernel (a graph replay cannot be timed from inside): that is roofline.kernel_ms.
-    PROFILE_EVERY = 8
+    # hipGraph.  A graph replay cannot be timed from inside: after the timed region the same steps are launched piece
+    # by piece with HIP events around every rollout kernel (roofline.kernel_ms).
+    EVENT_PASS_STEPS = 64
 
     def planning_step(i):
         # everything below is enqueued on one stream; there is no host synchronisation inside a step
         if not torch_exchange:
-            p.profile(timed[0] and i % PROFILE_EVERY == 0)
             p.plan(SEED, 1, 1, sptr)
             return
         p.local_partials(sptr)
@@ -231,7 +322,23 @@ def main():
         p.merge(gathered.data_ptr(), world, sptr)
         p.advance_noise(SEED, sptr)
 
-    timed = [False]
+    # the collective's cost, measured: the same shard planned by a handle of its own without the exchange (update from
+    # the local samples only), on rank 0 while the others wait
+    local_ms = None
+    if world > 1 and rank == 0:
+        p0 = make_planner(K_local, rank * K_local, local_rank)
+        for _ in range(5):
+            p0.plan(SEED, 1, 1, sptr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            p0.plan(SEED, 1, 1, sptr)
+        torch.cuda.synchronize()
+        local_ms = 1e3 * (time.perf_counter() - t0) / 50
+        p0.close()
+    if world > 1:
+        barrier()
+
     if sharded and not torch_exchange:
         # first step with the exchange captured in the graph; if the library cannot do it here, every rank fails the
         # same way and the run continues with the exchange made by torch.distributed (said so in the result line)
@@ -249,19 +356,22 @@ def main():
         p.generate_noise_step(SEED, sptr)
     for i in range(args.warmup):
         planning_step(i)
-    timed[0] = True
-    p.profile(torch_exchange)
-    p.profile_read()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         planning_step(i)
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms, launches = p.profile_read()
-    p.profile(False)
     log = p.read_log(args.steps + args.warmup)
     log_total = int(log["total"])
+    # rollout-kernel time: HIP events on the kernel's own stream around every launch of a pass of its own
+    p.profile(True)
+    p.profile_read()
+    for i in range(EVENT_PASS_STEPS):
+        planning_step(i)
+    torch.cuda.synchronize()
+    kernel_ms, launches = p.profile_read()
+    p.profile(False)
     log_dist = float(np.linalg.norm(log["hand"][-1] - log["target"][-1]))
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -309,6 +419,12 @@ def main():
                      "efficiency": t1_large / (world * tn_large),
                      "env_steps_per_sec": K_STRONG_LARGE * H / (tn_large * 1e-3)}
 
+    # One GPU: the other flavours of the planning step, outside the timed region (extra keys of the result line).
+    extras = {}
+    if world == 1 and not args.no_extras:
+        p.close()
+        extras = other_step_flavours(sptr)
+
     if rank == 0:
         env_steps = K_total * H * args.steps
         k_ms = kernel_ms / max(launches, 1)
@@ -334,6 +450,9 @@ def main():
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": measured_traffic() if K_local == K_PER_GPU else None,
                          "flop_per_env_step": flops, "kernel_ms": k_ms, "launches": launches,
+                         "kernel_ms_how": "HIP events on the planner's stream around every rollout launch of %d planning "
+                                          "steps issued piece by piece after the timed region" % EVENT_PASS_STEPS,
+                         **(issue_statistics(flops) if K_local == K_PER_GPU else {}),
                          "hbm": {"algorithmic_bytes_per_launch": bytes_launch,
                                  "achieved_GBs": bytes_launch / (k_ms * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": bytes_launch / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
@@ -342,6 +461,11 @@ def main():
             # T(1 GPU, K) / (N * T(N GPUs, K)), both measured in this run
             out["strong_scaling"] = {"K_total": K_total, "one_gpu_ms_per_step": t1_ms, "n_gpu_ms_per_step": ms_step,
                                      "efficiency": t1_ms / (world * ms_step)}
+        if local_ms is not None:
+            # what the collective costs: this rank's shard planned alone (no exchange) against the sharded step
+            out["exchange"] = {"shard_alone_ms_per_step": local_ms, "sharded_ms_per_step": ms_step,
+                               "exchange_ms": ms_step - local_ms, "how": exchange}
+        out.update(extras)
         if large is not None:
             out["strong_scaling_large"] = large
         if base is not None:

@@ -48,3 +48,40 @@ extern "C" void core_rollout(int f64, int model, const double* q0, const double*
     else                 { if (f64) GO(double, Tree18DofRk4); else GO(float, Tree18DofRk4); }
 }
 
+
+// Substep-by-substep record of one rollout of the arm, for studies of where fp32 and fp64 part ways:
+// out[(t * FRAME_SKIP + s) * 24 + ...] = q (7), v (7), weight withheld from every limit row (7: > 0 = the row exists
+// and ended inactive), contact (1), sweeps (1), unused (1)
+// exact_positions: the positions are carried in fp64 beside the step (q += h v' without rounding, what a compensated
+// summation would give at best) and handed to every substep rounded to T: isolates the share of the position
+// integration's rounding in a difference between the precisions
+template <class T>
+static void trace(const double* q0, const double* v0, const double* act, int H, double* out, bool exact_positions = false) {
+    using MD = Reacher7Dof;
+    using S = Step<T, MD>;
+    constexpr int NV = MD::NV;
+    T q[NV], v[NV];
+    double qx[NV];
+    for (int j = 0; j < NV; j++) { q[j] = T(q0[j]); v[j] = T(v0[j]); qx[j] = q0[j]; }
+    typename S::Active am;
+    am.reset();
+    for (int t = 0; t < H; t++) {
+        T a[NV];
+        for (int j = 0; j < NV; j++) a[j] = T(act[t * NV + j]);
+        for (int s = 0; s < MD::FRAME_SKIP; s++) {
+            typename S::Out o;
+            int sw = 0;
+            S::substep(q, v, a, false, o, am, sw);
+            if (exact_positions)
+                for (int j = 0; j < NV; j++) { qx[j] += MD::H * double(v[j]); q[j] = T(qx[j]); }
+            double* row = out + (size_t)(t * MD::FRAME_SKIP + s) * 24;
+            for (int j = 0; j < NV; j++) { row[j] = double(q[j]); row[7 + j] = double(v[j]); row[14 + j] = double(am.idle[j / 2][j % 2]); }
+            row[21] = double(am.idle_contact); row[22] = sw; row[23] = 0;
+        }
+    }
+}
+extern "C" void core_trace(int f64, const double* q0, const double* v0, const double* act, int H, double* out) {
+    if (f64 == 1) trace<double>(q0, v0, act, H, out);
+    else if (f64 == 2) trace<float>(q0, v0, act, H, out, true);
+    else trace<float>(q0, v0, act, H, out);
+}

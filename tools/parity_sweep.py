@@ -23,7 +23,8 @@ for case in range(40):
     span = hi - lo
     q0 = lo + span * rs.uniform(-0.05, 1.05, 7)          # also beyond the limits
     if case % 4 == 0:
-        q0[rs.randint(7)] = hi[rs.randint(7)] if rs.rand() < 0.5 else lo[rs.randint(7)]   # something exactly on a limit value
+        upper, j = rs.rand() < 0.5, rs.randint(7)
+        q0[j] = hi[j] if upper else lo[j]                      # one joint exactly on one of its own limit values
     v0 = rs.normal(0, [0.0, 0.5, 2.0, 6.0][case % 4], 7)
     tgt = rs.uniform(-0.3, 0.3, 3)
     if case % 5 == 0:
@@ -47,5 +48,6 @@ for case in range(40):
             frac_bad = float((es > 1e-2).mean())
             worst["f32_R"] = max(worst["f32_R"], eR); worst["f32_state"] = max(worst["f32_state"], float(np.median(es)))
             assert st & 1 == 0 and np.isfinite(R).all(), (case, st)
+            print("case %2d f32 rel dR %.2e median state err %.2e p99 %.2e frac>1e-4 %.4f" % (case, eR, np.median(es), np.percentile(es, 99), float((es > 1e-4).mean())), flush=True)
             if eR > 1e-4: print("case %2d  |v0| %.1f scale %.1f  f32: rel dR %.2e, median state err %.2e, samples off by > 1e-2: %.3f, status %d" % (case, np.abs(v0).max(), scale, eR, np.median(es), frac_bad, st), flush=True)
 print("worst", worst)

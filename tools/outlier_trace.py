@@ -15,7 +15,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import ref_mppi                     # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from sweep_cases import cases                   # noqa: E402
 from trajopt_amd.model import get_model         # noqa: E402
 
 SRC, OUT = os.path.join(ROOT, "tests", "host_core_harness.cpp"), os.path.join(ROOT, "tests", "_host_core.so")
@@ -30,29 +31,8 @@ AS_SWEPT_IN_ROUND_2 = "--as-swept" in sys.argv
 
 
 def sweep_cases(last):
-    """The sweep's cases 0 .. last, drawn exactly as tools/parity_sweep.py draws them."""
-    rs = np.random.RandomState(0)
-    for case in range(last + 1):
-        span = hi - lo
-        q0 = lo + span * rs.uniform(-0.05, 1.05, 7)
-        if case % 4 == 0:
-            if AS_SWEPT_IN_ROUND_2:
-                # the sweep of that round drew the joint that receives the value and the joint whose limit is the value
-                # separately (condition first, then the value's index, then the target's index)
-                upper = rs.rand() < 0.5
-                src, dst = rs.randint(7), rs.randint(7)
-                q0[dst] = hi[src] if upper else lo[src]
-            else:
-                upper, j = rs.rand() < 0.5, rs.randint(7)
-                q0[j] = hi[j] if upper else lo[j]
-        v0 = rs.normal(0, [0.0, 0.5, 2.0, 6.0][case % 4], 7)
-        tgt = rs.uniform(-0.3, 0.3, 3)
-        if case % 5 == 0:
-            q0[1] = 1.2; q0[3] = -0.3
-        scale = [0.3, 1.0, 3.0][case % 3]
-        raw = rs.normal(0, scale, (K, H, 7))
-        base = rs.normal(0, 0.5, (H, 7))
-        act = base + ref_mppi.filter_noise(raw.copy(), [np.ones(7), 0.25, 0.8, 0.0])
+    """The sweep's cases 0 .. last (tests/sweep_cases.py): (case, q0, v0, actions)."""
+    for case, q0, v0, tgt, raw, base, act in cases(md, last + 1, K, H, AS_SWEPT_IN_ROUND_2):
         yield case, q0, v0, act
 
 
@@ -63,11 +43,31 @@ def trace(f64, q0, v0, act):
     return out
 
 
+WIDTH = 0.001            # solimp width of the model: the impedance rises over the first milliradian of a violation
+
+
+def jump_cause(a, b, err):
+    """What stands at the largest multiplicative jump of the difference between the precisions: (substep, cause)."""
+    ratio = err[1:] / np.maximum(err[:-1], 1e-9)
+    s = int(np.argmax(ratio)) + 1                       # the substep whose result jumped
+    pen_a = np.minimum(a[:, :7] - lo, hi - a[:, :7])
+    pen_b = np.minimum(b[:, :7] - lo, hi - b[:, :7])
+    w = slice(max(0, s - 2), s + 1)                     # states the substep started from and ended in
+    if ((pen_a[w] < 0) != (pen_b[w] < 0)).any():
+        return s, "row exists in one precision only"
+    if ((a[w, 14:22] > 0) != (b[w, 14:22] > 0)).any():
+        return s, "row active in one precision only"
+    if ((pen_a[w] < 0) & (pen_a[w] > -WIDTH)).any() or ((pen_b[w] < 0) & (pen_b[w] > -WIDTH)).any():
+        return s, "row inside the impedance ramp"
+    return s, "smooth"
+
+
 def survey():
-    """All 40 cases: per case the number of samples that end more than 1e-4 apart and what the first difference was.
-    --exact-positions: the fp32 side integrates its positions without rounding (see the harness)."""
+    """All 40 cases: per case the number of samples that end more than 1e-4 apart and what stands at the largest jump
+    of the difference.  --exact-positions: the fp32 side integrates its positions without rounding (see the harness)."""
     f32 = 2 if "--exact-positions" in sys.argv else 0
-    tot = {"samples": 0, "apart": 0, "row exists in one precision only": 0, "row active in one precision only": 0, "smooth": 0}
+    causes = ["row exists in one precision only", "row active in one precision only", "row inside the impedance ramp", "smooth"]
+    tot = dict({"samples": 0, "apart": 0}, **{c: 0 for c in causes})
     finals = []
     for case, q0, v0, act in sweep_cases(39):
         apart = []
@@ -77,15 +77,7 @@ def survey():
             finals.append(err[-1])
             if err[-1] <= 1e-4:
                 continue
-            s = np.nonzero(err > 1e-5)[0][0]
-            w = slice(max(0, s - 3), s + 1)
-            out_a, out_b = (a[:, :7] < lo) | (a[:, :7] > hi), (b[:, :7] < lo) | (b[:, :7] > hi)
-            if (out_a[w] != out_b[w]).any():
-                apart.append("row exists in one precision only")
-            elif ((a[w, 14:22] > 0) != (b[w, 14:22] > 0)).any():
-                apart.append("row active in one precision only")
-            else:
-                apart.append("smooth")
+            apart.append(jump_cause(a, b, err)[1])
         tot["samples"] += K
         tot["apart"] += len(apart)
         for c in apart:

@@ -533,3 +533,38 @@ def test_noise_drawn_in_the_advance_launch_gives_the_same_trajectory(dev_model, 
     assert np.array_equal(a.act_sequence(), c.act_sequence())
     for p in ps:
         p.close()
+
+
+@pytest.mark.parametrize("dtype,H,P,K", [("f32", 16, 64, 512), ("f64", 32, 32, 192), ("f32", 70, 16, 1000)])
+def test_update_from_noise_drawn_again_equals_the_update_from_stored_noise(dev_model, dtype, H, P, K):
+    """Batched planners on device noise update their act_sequence without reading the noise back: every block draws
+    its samples' perturbations again (same counters, same key) and sums them in the order the stored-noise kernel
+    uses.  Both routes must give act_sequence, arg-max, best return and the shard statistics bit for bit: one
+    iteration, a second one from the updated sequence, and whole planning steps replayed from the captured graph."""
+    import os
+    rs = np.random.RandomState(H + P)
+    res = []
+    for regen in ("1", "0"):
+        os.environ["MPPI_UPDATE_REGEN"] = regen
+        try:
+            p = _planner(dev_model, K, H, dtype, planners=P)
+            p.set_params(25.0, 0.97, "dense")
+            q0, v0 = 0.3 * rs.randn(P, 7) if regen == "1" else q0, rs.randn(P, 7) if regen == "1" else v0
+            tgt = 0.2 * rs.rand(P, 3) if regen == "1" else tgt
+            base = 0.2 * rs.randn(P, H, 7) if regen == "1" else base
+            p.set_start_state(q0, v0, tgt, 3)
+            p.set_base_actions(base)
+            p.generate_noise(17)
+            p.iterate(2)
+            out = [p.act_sequence(), p.argmax(), p.rmax()]
+            p.generate_noise_step(5)
+            p.local_partials()
+            out.append(p.partials())
+            p.plan(9, 1, 3)
+            out += [p.act_sequence(), p.read_log(3, planner=P - 1)["qpos"]]
+            res.append(out)
+            p.close()
+        finally:
+            os.environ.pop("MPPI_UPDATE_REGEN", None)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)

@@ -253,6 +253,8 @@ q.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - 1)            # the
 q.advance()
 q.synchronize()
 assert q.status() & 4 == 4, q.status()
+p.close()
+q.close()
 """
     import os
     import tempfile
@@ -260,7 +262,9 @@ assert q.status() & 4 == 4, q.status()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "r.npy")
         env = dict(os.environ, MPPI_NO_HOST_REF_CHECK="1")
-        subprocess.run([sys.executable, "-c", code % root, out], check=True, env=env, timeout=110)
+        done = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code % root, out], env=env, timeout=110,
+                              stderr=subprocess.PIPE, text=True)
+        assert done.returncode == 0, done.stderr[-3000:]
         got = np.load(out)
     H, T, K = 4, 9, 64
     acts, rew = got[:K * H * 7].reshape(K, H, 7), got[K * H * 7:].reshape(K, H)

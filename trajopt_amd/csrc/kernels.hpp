@@ -94,12 +94,54 @@ __global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restri
     }
 }
 
-// one lane per (sample k, action dimension j): counter = (global k, j, block c, 0), block c holds the
-// draws of steps 4c .. 4c+3.  With seed_from_state the stream key is seed + the planner's current
-// timestep (the reference re-seeds every planning step with seed + t, trajopt/algos/mppi.py:130-132)
+// The filtered perturbation of one (sample, action dimension) along the horizon, from the counter-based stream:
+// counter = (global sample index, dimension, block c, planner), key = the stream key; block c holds the draws of steps
+// 4c .. 4c+3.  emit(t, e) receives every step's value in fp64.  The noise kernels store it; the update that draws its
+// noise again instead of reading it back calls the same function, so both see the same bits (every product and sum
+// below is spelled out as the instruction it is to be, so that the two kernels cannot be contracted differently).
+// one block of four steps (see philox_sequence)
+template <class F>
+__device__ __forceinline__ void philox_sequence_block(int c, uint32_t kglobal, int j, int pl, uint32_t key_lo, uint32_t key_hi,
+                                                      int H, double sigma, const FilterCoefs& fc, double& e1, double& e2, F&& emit) {
+    uint32_t ctr[4] = {kglobal, (uint32_t)j, (uint32_t)c, (uint32_t)pl};
+    philox4x32_10(ctr, key_lo, key_hi);
+    float z[4];
+    box_muller(ctr[0], ctr[1], z[0], z[1]);
+    box_muller(ctr[2], ctr[3], z[2], z[3]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int t = 4 * c + u;
+        if (t < H) {
+            double e = __dmul_rn((double)z[u], sigma);
+            if (t >= 2) e = fma(fc.b0, e, fma(fc.b1, e1, __dmul_rn(fc.b2, e2)));
+            e2 = e1;
+            e1 = e;
+            emit(t, e);
+        }
+    }
+}
+// HT = 0: any horizon (a loop); HT > 0: horizons up to HT, fully unrolled, so that t is a constant in every call of emit
+template <int HT, class F>
+__device__ __forceinline__ void philox_sequence(uint32_t kglobal, int j, int pl, uint32_t key_lo, uint32_t key_hi, int H,
+                                                const FilterCoefs& fc, F&& emit) {
+    const double sigma = fc.sigma[j];
+    double e1 = 0.0, e2 = 0.0;
+    if constexpr (HT == 0) {
+        for (int c = 0; 4 * c < H; c++) philox_sequence_block(c, kglobal, j, pl, key_lo, key_hi, H, sigma, fc, e1, e2, emit);
+    } else {
+#pragma unroll
+        for (int c = 0; c < (HT + 3) / 4; c++)
+            if (4 * c < H) philox_sequence_block(c, kglobal, j, pl, key_lo, key_hi, H, sigma, fc, e1, e2, emit);
+    }
+}
+
+// one lane per (sample k, action dimension j).  With seed_from_state the stream key is seed + the planner's current
+// timestep (the reference re-seeds every planning step with seed + t, trajopt/algos/mppi.py:130-132).  The key used
+// is left in key_out[2 * planner ..] for kernels that draw the same noise again.
 template <class T, int NV>
 __device__ __forceinline__ void noise_philox_block(int block, int pl, int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
-                                                   int step, int seed_from_state, const FilterCoefs& fc, T* __restrict__ eps) {
+                                                   int step, int seed_from_state, const FilterCoefs& fc, T* __restrict__ eps,
+                                                   uint32_t* __restrict__ key_out) {
     const int idx = block * 256 + threadIdx.x;
     if (idx >= K * NV) return;
     const int j = idx / K, k = idx - j * K;
@@ -109,32 +151,15 @@ __device__ __forceinline__ void noise_philox_block(int block, int pl, int K, int
         seed_lo = (uint32_t)s;
         seed_hi = (uint32_t)(s >> 32);
     }
-    const double sigma = fc.sigma[j];
-    double e1 = 0.0, e2 = 0.0;
-    for (int c = 0; 4 * c < H; c++) {
-        uint32_t ctr[4] = {(uint32_t)(k_offset + k), (uint32_t)j, (uint32_t)c, (uint32_t)pl};
-        philox4x32_10(ctr, seed_lo, seed_hi);
-        float z[4];
-        box_muller(ctr[0], ctr[1], z[0], z[1]);
-        box_muller(ctr[2], ctr[3], z[2], z[3]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = 4 * c + u;
-            if (t < H) {
-                double e = (double)z[u] * sigma;
-                if (t >= 2) e = fc.b0 * e + fc.b1 * e1 + fc.b2 * e2;
-                e2 = e1;
-                e1 = e;
-                eps[((size_t)t * NV + j) * K + k] = T(e);
-            }
-        }
-    }
+    if (idx == 0) { key_out[2 * pl] = seed_lo; key_out[2 * pl + 1] = seed_hi; }
+    philox_sequence<0>((uint32_t)(k_offset + k), j, pl, seed_lo, seed_hi, H, fc,
+                       [&](int t, double e) { eps[((size_t)t * NV + j) * K + k] = T(e); });
 }
 template <class T, int NV>
 __global__ void __launch_bounds__(256) noise_philox_kernel(int K, int H, int k_offset, uint32_t seed_lo, uint32_t seed_hi,
                                                            const DevState* __restrict__ st, int seed_from_state,
-                                                           FilterCoefs fc, T* __restrict__ eps) {
-    noise_philox_block<T, NV>(blockIdx.x, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, st[blockIdx.y].timestep, seed_from_state, fc, eps);
+                                                           FilterCoefs fc, T* __restrict__ eps, uint32_t* __restrict__ key_out) {
+    noise_philox_block<T, NV>(blockIdx.x, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, st[blockIdx.y].timestep, seed_from_state, fc, eps, key_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -395,9 +420,9 @@ __global__ void __launch_bounds__(256) advance_noise_kernel(DevState* __restrict
                                                             int* __restrict__ log_count, double* __restrict__ last_row,
                                                             int* __restrict__ status, int K, int k_offset, uint32_t seed_lo,
                                                             uint32_t seed_hi, const int* __restrict__ next_step, FilterCoefs fc,
-                                                            T* __restrict__ eps) {
+                                                            T* __restrict__ eps, uint32_t* __restrict__ key_out) {
     if (blockIdx.x == 0) advance_block<MD>(blockIdx.y, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status);
-    else noise_philox_block<T, MD::NV>(blockIdx.x - 1, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, next_step[blockIdx.y], 1, fc, eps);
+    else noise_philox_block<T, MD::NV>(blockIdx.x - 1, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, next_step[blockIdx.y], 1, fc, eps, key_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -627,7 +652,7 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
             if (k < K) {
                 const double sk = exp(kappa * ((double)rv[e] - bv));
 #pragma unroll
-                for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk * (double)ev[j][e];
+                for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] = fma(sk, (double)ev[j][e], acc[j]);
                 acc[ROWS] += sk;
             }
         }
@@ -648,14 +673,14 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
             for (int u = 0; u < U; u++) {
                 if (!weights) sk[u] = exp(kappa * (sk[u] - bv));
 #pragma unroll
-                for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk[u] * (double)e[j][u];
+                for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] = fma(sk[u], (double)e[j][u], acc[j]);
                 acc[ROWS] += sk[u];
             }
         }
         for (; k < K; k += nthreads) {
             const double sk = weights ? weights[k] : exp(kappa * ((double)R[k] - bv));
 #pragma unroll
-            for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] += sk * (double)eps[(size_t)j * K + k];
+            for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] = fma(sk, (double)eps[(size_t)j * K + k], acc[j]);
             acc[ROWS] += sk;
         }
     }
@@ -679,6 +704,75 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
         part[3 + row0 + tid] = n;
     }
     if (blockIdx.x == 0 && tid == 0) {
+        part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
+        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + bi); }
+    }
+}
+
+// The update of batched planners without reading the noise back: a block owns one action dimension j of one planner
+// and ALL steps; every thread draws the perturbations of its samples again (philox_sequence with the key the noise
+// kernel left behind: the same bits the rollouts read) and keeps one running sum per step.  Each sum is formed in the
+// order update_rows_kernel uses for the same launch shape -- a thread's samples k = tid, tid + blockDim, ... in turn,
+// the wave's lanes by the exclusive-or tree, the waves in turn -- so act_sequence comes out bit for bit as from the
+// stored noise; what changes is the memory traffic (no read of eps: a third of the bytes of a batched planning step).
+// HT: compile-time bound on the horizon (one fp64 running sum per step in registers).
+template <class T, int NV, int HT>
+__global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__ R, int K, int H, double kappa, int k_offset,
+                                                           int write_base, double* __restrict__ base, double* __restrict__ part,
+                                                           double* __restrict__ result, const uint32_t* __restrict__ key,
+                                                           FilterCoefs fc) {
+    __shared__ double s_v[4][HT + 1];
+    __shared__ int s_i[4];
+    const int j = blockIdx.x, pl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HM = H * NV;
+    R += (size_t)pl * K;
+    base += (size_t)pl * HM; part += (size_t)pl * (3 + HM); result += 2 * pl;
+    const uint32_t key_lo = key[2 * pl], key_hi = key[2 * pl + 1];
+    // Rmax and the first arg-max, as every block of update_rows_kernel finds them
+    double bv = -DBL_MAX;
+    int bi = INT_MAX;
+    for (int k = tid; k < K; k += 256) argmax_combine(bv, bi, (double)R[k], k);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = shfl_xor_d(bv, m);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (lane == 0) { s_v[wave][0] = bv; s_i[wave] = bi; }
+    __syncthreads();
+    bv = s_v[0][0]; bi = s_i[0];
+    for (int w = 1; w < 4; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
+    __syncthreads();
+    double acc[HT + 1];              // [HT]: sum of the weights
+#pragma unroll
+    for (int t = 0; t <= HT; t++) acc[t] = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const double sk = exp(kappa * ((double)R[k] - bv));
+        // (fully unrolled: t is a constant in every call, the running sums stay in registers)
+        philox_sequence<HT>((uint32_t)(k_offset + k), j, pl, key_lo, key_hi, H, fc,
+                            [&](int t, double e) { acc[t] = fma(sk, (double)(T)e, acc[t]); });
+        acc[HT] += sk;
+    }
+#pragma unroll
+    for (int t = 0; t <= HT; t++) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[t] += shfl_xor_d(acc[t], m);
+        if (lane == 0) s_v[wave][t] = acc[t];
+    }
+    __syncthreads();
+    for (int t = tid; t <= HT; t += 256) {
+        double tot = 0.0;
+        for (int w = 0; w < 4; w++) tot += s_v[w][t];
+        s_v[0][t] = tot;                   // only this thread reads column t of the other rows
+    }
+    __syncthreads();
+    const double d = s_v[0][HT];
+    for (int t = tid; t < H; t += 256) {
+        const double n = s_v[0][t];
+        if (write_base) base[t * NV + j] = (base[t * NV + j] * d + n) / (d + 1e-6);
+        part[3 + t * NV + j] = n;
+    }
+    if (j == 0 && tid == 0) {
         part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
         if (write_base) { result[0] = bv; result[1] = (double)(k_offset + bi); }
     }
@@ -729,14 +823,19 @@ struct ModelOps {
     hipError_t (*rollout)(int dtype, const RolloutArgs&, hipStream_t);
     hipError_t (*noise_upload)(int dtype, const double* raw, int K, int H, int P, const FilterCoefs&, int filter, void* eps, hipStream_t);
     hipError_t (*noise_philox)(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st, int seed_from_state,
-                               const FilterCoefs&, void* eps, hipStream_t);
+                               const FilterCoefs&, void* eps, uint32_t* key_out, hipStream_t);
     hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                           const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
     hipError_t (*critic)(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t);
     hipError_t (*advance_noise)(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                 const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status,
-                                int K, int k_offset, uint64_t seed, const int* next_step, const FilterCoefs& fc, void* eps, hipStream_t);
+                                int K, int k_offset, uint64_t seed, const int* next_step, const FilterCoefs& fc, void* eps,
+                                uint32_t* key_out, hipStream_t);
+    // the update of batched planners from noise drawn again (update_regen_kernel); false: no kernel for this shape
+    bool (*update_regen_fits)(int K, int H, int P);
+    hipError_t (*update_regen)(int dtype, const void* R, int K, int H, int P, double kappa, int k_offset, int write_base, double* base,
+                               double* part, double* result, const uint32_t* key, const FilterCoefs& fc, hipStream_t);
     hipError_t (*update_rows)(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset, int write_base, double* weights, double* base,
                               double* part, double* result, hipStream_t);
 };
@@ -822,13 +921,29 @@ static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H
 }
 template <class MD>
 static hipError_t launch_noise_philox(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st,
-                                      int seed_from_state, const FilterCoefs& fc, void* eps, hipStream_t s) {
+                                      int seed_from_state, const FilterCoefs& fc, void* eps, uint32_t* key_out, hipStream_t s) {
     const dim3 grid((K * MD::NV + 255) / 256, P), block(256);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((noise_philox_kernel<float, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (float*)eps);
+        hipLaunchKernelGGL((noise_philox_kernel<float, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (float*)eps, key_out);
     else
-        hipLaunchKernelGGL((noise_philox_kernel<double, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (double*)eps);
+        hipLaunchKernelGGL((noise_philox_kernel<double, MD::NV>), grid, block, 0, s, K, H, k_offset, lo, hi, st, seed_from_state, fc, (double*)eps, key_out);
+    return hipGetLastError();
+}
+// the shape update_rows_kernel serves with one block of 256 threads per step: many planners, at most 1024 samples each
+inline bool update_regen_fits(int K, int H, int P) { return (long)H * P >= 1024 && K <= 1024 && H <= 128; }
+template <class MD>
+static hipError_t launch_update_regen(int dtype, const void* R, int K, int H, int P, double kappa, int k_offset, int write_base,
+                                      double* base, double* part, double* result, const uint32_t* key, const FilterCoefs& fc,
+                                      hipStream_t s) {
+    constexpr int NV = MD::NV;
+    const dim3 grid(NV, P), block(256);
+#define MPPI_LAUNCH_REGEN(T_, HT_)                                                                                            \
+    hipLaunchKernelGGL((update_regen_kernel<T_, NV, HT_>), grid, block, 0, s, (const T_*)R, K, H, kappa, k_offset, write_base, \
+                       base, part, result, key, fc)
+    if (dtype == MPPI_F32) { if (H <= 64) MPPI_LAUNCH_REGEN(float, 64); else MPPI_LAUNCH_REGEN(float, 128); }
+    else { if (H <= 64) MPPI_LAUNCH_REGEN(double, 64); else MPPI_LAUNCH_REGEN(double, 128); }
+#undef MPPI_LAUNCH_REGEN
     return hipGetLastError();
 }
 template <class MD>
@@ -843,15 +958,15 @@ template <class MD>
 static hipError_t launch_advance_noise(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P,
                                        int tail_mode, const double* mean, double* log, int log_cap, int* log_count,
                                        double* last_row, int* status, int K, int k_offset, uint64_t seed, const int* next_step,
-                                       const FilterCoefs& fc, void* eps, hipStream_t s) {
+                                       const FilterCoefs& fc, void* eps, uint32_t* key_out, hipStream_t s) {
     const dim3 grid(1 + (K * MD::NV + 255) / 256, P), block(256);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((advance_noise_kernel<float, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (float*)eps);
+                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (float*)eps, key_out);
     else
         hipLaunchKernelGGL((advance_noise_kernel<double, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (double*)eps);
+                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (double*)eps, key_out);
     return hipGetLastError();
 }
 template <class MD>
@@ -869,7 +984,9 @@ static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int d
     return hipGetLastError();
 }
 // more samples than a block holds in registers, few planners: the weights are worth evaluating once
-inline bool update_wants_weights(int K, int H, int P) { return K > 4096 && (long)H * P < 1024; }
+// ... and so are they for batched planners, whose update has one block per step: H blocks would evaluate the same K
+// exponentials each
+inline bool update_wants_weights(int K, int H, int P) { return (K > 4096 && (long)H * P < 1024) || ((long)H * P >= 1024 && K >= 64); }
 // weights: scratch of P * (K + 2) doubles for update_weights_kernel, or null (every block evaluates the weights itself)
 template <class MD>
 static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset,
@@ -891,7 +1008,7 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
     const int cus = 256;
     const double* w = nullptr;
     if (weights && update_wants_weights(K, H, P)) {
-        const dim3 wgrid(K >= 262144 ? 64 : 32, P);
+        const dim3 wgrid(K >= 262144 ? 64 : (K > 4096 ? 32 : 1), P);
         if (dtype == MPPI_F32) hipLaunchKernelGGL((update_weights_kernel<float>), wgrid, dim3(1024), 0, s, (const float*)R, K, kappa, weights);
         else hipLaunchKernelGGL((update_weights_kernel<double>), wgrid, dim3(1024), 0, s, (const double*)R, K, kappa, weights);
         w = weights;
@@ -905,5 +1022,6 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
 }
 template <class MD> static ModelOps make_ops() {
     return {MD::name, MD::NV, MD::NQ, &model_matches<MD>, &launch_rollout<MD>, &launch_noise_upload<MD>, &launch_noise_philox<MD>,
-            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_advance_noise<MD>, &launch_update_rows<MD>};
+            &launch_advance<MD>, &launch_env_step<MD>, &launch_critic<MD>, &launch_advance_noise<MD>, &update_regen_fits,
+            &launch_update_regen<MD>, &launch_update_rows<MD>};
 }

@@ -27,6 +27,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -311,6 +312,8 @@ struct mppi_planner {
     double* d_last_row;    // [P][3M+7] the newest log row of every planner (mppi_read_step)
     double* h_step;        // page-locked [P][3M+7 + H*M]: where mppi_read_step lands its two copies
     int* d_next_step;      // [P] index of the planning step after the one being rolled out
+    uint32_t* d_noise_key; // [P][2] stream key the Philox noise in d_eps was drawn with (written by the noise kernels)
+    bool eps_philox;       // d_eps holds Philox noise (the update may draw it again instead of reading it)
     bool noise_ahead;      // eps already holds the Philox noise of the coming planning step ...
     uint64_t noise_ahead_seed;   // ... drawn with this seed
     int explicit_act;
@@ -336,6 +339,12 @@ struct mppi_planner {
 };
 
 static hipStream_t pick(mppi_planner* p, void* s) { return s ? (hipStream_t)s : p->stream; }
+
+// where the noise in d_eps comes from decides which update kernel a captured iteration holds
+static void set_eps_source(mppi_planner* p, bool philox) {
+    if (p->eps_philox != philox) p->cfg_gen++;
+    p->eps_philox = philox;
+}
 
 // Input arrays may be host memory or device memory (a torch tensor's data_ptr()): bulk copies use hipMemcpyDefault,
 // which takes the direction from the addresses; the few small arrays the host itself has to look at come through here.
@@ -401,6 +410,8 @@ static int planner_allocate(mppi_planner* p) {
     HIP_OK(hipMemset(p->d_log_count, 0, 4 * P));
     HIP_OK(hipMalloc(&p->d_next_step, 4 * P));
     HIP_OK(hipMemset(p->d_next_step, 0, 4 * P));
+    HIP_OK(hipMalloc(&p->d_noise_key, 8 * P));
+    HIP_OK(hipMemset(p->d_noise_key, 0, 8 * P));
     HIP_OK(hipMalloc(&p->d_last_row, P * (p->nq + 2 * p->nv + 7) * 8));
     HIP_OK(hipMemset(p->d_last_row, 0, P * (p->nq + 2 * p->nv + 7) * 8));
     HIP_OK(hipHostMalloc(&p->h_step, (P * (p->nq + 2 * p->nv + 7) + HM) * 8, hipHostMallocDefault));
@@ -514,7 +525,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     if (p->ev_upload_done) (void)hipEventDestroy(p->ev_upload_done);
     if (p->d_weights) (void)hipFree(p->d_weights);
     void* bufs[] = {p->d_state, p->d_base, p->d_base_tmp, p->d_mean, p->d_eps, p->d_raw, p->d_ref, p->d_R,
-                    p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step, p->d_last_row};
+                    p->d_part_alloc ? p->d_part_alloc : p->d_part, p->d_result, p->d_obs, p->d_rew, p->d_status, p->d_log, p->d_log_count, p->d_fobs, p->d_critic, p->d_next_step, p->d_last_row, p->d_noise_key};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -645,6 +656,7 @@ int mppi_upload_noise(mppi_planner* p, const double* raw, void* stream) try {
     HIP_OK(hipStreamSynchronize(s));     // the host buffer may be reused by the caller
     p->explicit_act = 0;
     p->noise_ahead = false;
+    set_eps_source(p, false);
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -709,6 +721,7 @@ int mppi_commit_noise(mppi_planner* p, void* stream) try {
     p->raw_pending = false;
     p->explicit_act = 0;
     p->noise_ahead = false;
+    set_eps_source(p, false);
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -718,9 +731,10 @@ static int generate_noise(mppi_planner* p, uint64_t seed, int seed_from_state, v
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->P, p->cfg.k_offset, seed, p->d_state, seed_from_state,
-                                       p->fc, p->d_eps, pick(p, stream)));
+                                       p->fc, p->d_eps, p->d_noise_key, pick(p, stream)));
     p->explicit_act = 0;
     p->noise_ahead = false;
+    set_eps_source(p, true);
     return 0;
 }
 int mppi_generate_noise(mppi_planner* p, uint64_t seed, void* stream) { return generate_noise(p, seed, 0, stream); }
@@ -749,8 +763,9 @@ int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) try {
     HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
                                         p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
                                         p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps,
-                                        pick(p, stream)));
+                                        p->d_noise_key, pick(p, stream)));
     for (DevState& st : *p->h_state) st.timestep++;
+    set_eps_source(p, true);
     p->explicit_act = 0;
     p->noise_ahead = true;
     p->noise_ahead_seed = seed;
@@ -796,6 +811,7 @@ int mppi_upload_actions(mppi_planner* p, const double* act, void* stream) try {
     HIP_OK(hipStreamSynchronize(s));
     p->explicit_act = 1;
     p->noise_ahead = false;
+    set_eps_source(p, false);
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -831,13 +847,33 @@ static int launch_rollout_only(mppi_planner* p, hipStream_t s) {
     return 0;
 }
 
+// true if the update draws the noise again instead of reading it (batched planners on device noise).  Both routes give the
+// same bits; drawing a normal again costs a CU about as long as HBM takes to deliver a stored one (283 against 276 us at
+// 1024 planners x 512 samples), so the stored-noise kernel stays the default and MPPI_UPDATE_REGEN=1 selects this one
+// (a planner whose noise buffer could be dropped would need it).
+static bool update_regenerates(const mppi_planner* p) {
+    const char* e = getenv("MPPI_UPDATE_REGEN");        // (looked up at every launch or capture: tests flip it)
+    const bool allowed = e && e[0] == '1';
+    return allowed && p->eps_philox && !p->explicit_act && p->model->ops->update_regen_fits(p->cfg.K, p->cfg.H, p->P);
+}
+
 static int launch_partials(mppi_planner* p, hipStream_t s) {
+    if (update_regenerates(p)) {
+        HIP_OK(p->model->ops->update_regen(p->cfg.dtype, p->d_R, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 0, p->d_base,
+                                           p->d_part, p->d_result, p->d_noise_key, p->fc, s));
+        return 0;
+    }
     HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 0,
                                       p->d_weights, p->d_base, p->d_part, p->d_result, s));
     return 0;
 }
 
 static int launch_update_fused(mppi_planner* p, hipStream_t s) {
+    if (update_regenerates(p)) {
+        HIP_OK(p->model->ops->update_regen(p->cfg.dtype, p->d_R, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 1, p->d_base,
+                                           p->d_part, p->d_result, p->d_noise_key, p->fc, s));
+        return 0;
+    }
     HIP_OK(p->model->ops->update_rows(p->cfg.dtype, p->d_R, p->d_eps, p->cfg.K, p->cfg.H, p->P, p->cfg.kappa, p->cfg.k_offset, 1,
                                       p->d_weights, p->d_base, p->d_part, p->d_result, s));
     return 0;
@@ -973,7 +1009,8 @@ static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStrea
     if (plan_draws_ahead(p))
         HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
                                             p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
-                                            p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps, s));
+                                            p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps,
+                                            p->d_noise_key, s));
     else
         HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act,
                                       p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, s));
@@ -981,7 +1018,7 @@ static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStrea
 }
 static int enqueue_plan_noise(mppi_planner* p, uint64_t seed, hipStream_t s) {
     HIP_OK(p->model->ops->noise_philox(p->cfg.dtype, p->cfg.K, p->cfg.H, p->P, p->cfg.k_offset, seed, p->d_state, 1, p->fc,
-                                       p->d_eps, s));
+                                       p->d_eps, p->d_noise_key, s));
     return 0;
 }
 
@@ -996,6 +1033,7 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
     p->explicit_act = 0;
+    set_eps_source(p, true);
     const bool ahead = plan_draws_ahead(p);
     // with noise drawn ahead only the first step of a run needs a launch of its own
     const bool have_noise = ahead && p->noise_ahead && p->noise_ahead_seed == seed;
@@ -1176,11 +1214,21 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) try {
             }
         };
         const size_t nthreads = jobs >= 32 ? 8 : 1, per = (jobs + nthreads - 1) / nthreads;
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nthreads; t++)
-            if (t * per < jobs) pool.emplace_back(run, t * per, (t + 1) * per < jobs ? (t + 1) * per : jobs);
-        run(0, per < jobs ? per : jobs);
-        for (auto& th : pool) th.join();
+        {
+            // helpers are joined on every way out; a helper that cannot be started leaves its share to this thread
+            struct Pool {
+                std::vector<std::thread> threads;
+                ~Pool() { for (auto& t : threads) if (t.joinable()) t.join(); }
+            } pool;
+            size_t started = 1;
+            try {
+                for (; started < nthreads && started * per < jobs; started++)
+                    pool.threads.emplace_back(run, started * per, (started + 1) * per < jobs ? (started + 1) * per : jobs);
+            } catch (const std::system_error&) {
+            }
+            run(0, per < jobs ? per : jobs);
+            if (started < nthreads && started * per < jobs) run(started * per, jobs);
+        }
         return 0;
     }
     case MPPI_READ_NEXT_OBS:

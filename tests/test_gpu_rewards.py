@@ -220,55 +220,42 @@ def test_end_of_the_reference_through_the_c_abi(dm):
     p.close()
 
 
-def test_device_reports_the_end_of_the_reference(oracle_sim):
+def test_device_reports_the_end_of_the_reference(oracle_sim, monkeypatch):
     """The kernels' own report of the same event.  The library's host-side check is switched off by its test hook
-    (in a child process: the hook is read once), a rollout and an advance then index past the end of the reference:
-    both finish, the status word carries MPPI_STATUS_REF_END, and the rewards are those of the last row."""
-    import subprocess
-    import sys
-    code = r"""
-import numpy as np, sys
-sys.path.insert(0, %r)
-from trajopt_amd.device import DeviceModel, DevicePlanner
-H, T = 4, 9
-ref = np.cumsum(np.ones((T, 3)) * 0.01, axis=0)
-p = DevicePlanner(DeviceModel.get("reacher_7dof"), 64, H, kappa=25.0, sigma=np.ones(7), betas=(0.25, 0.8, 0.0),
-                  default_act="mean", reward_type="tracking", dtype="f64", dump=True)
-p.set_params(25.0, 1.0, "tracking")
-p.set_reference(ref, 1.0)
-p.set_base_actions(np.zeros((H, 7)))
-p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - H - 1)
-p.generate_noise(1)
-p.rollout()
-assert p.status() & 4 == 0, "a rollout that fits must not set the bit"
-p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - H + 1)        # indices 7, 8, 9, 10 of 9 rows
-p.rollout()
-assert p.status() & 4 == 4, p.status()
-np.save(sys.argv[1], np.concatenate([p.actions().ravel(), p.rewards().ravel()]))
-q = DevicePlanner(DeviceModel.get("reacher_7dof"), 8, H, default_act="mean", reward_type="tracking", dtype="f64")
-q.set_params(1.0, 1.0, "tracking")
-q.set_reference(ref, 1.0)
-q.set_base_actions(np.zeros((H, 7)))
-q.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - 1)            # the real env would read row 9
-q.advance()
-q.synchronize()
-assert q.status() & 4 == 4, q.status()
-p.close()
-q.close()
-"""
-    import os
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "r.npy")
-        env = dict(os.environ, MPPI_NO_HOST_REF_CHECK="1")
-        done = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code % root, out], env=env, timeout=110,
-                              stderr=subprocess.PIPE, text=True)
-        assert done.returncode == 0, done.stderr[-3000:]
-        got = np.load(out)
+    (an environment variable the library looks up at every call), a rollout and an advance then index past the end
+    of the reference: both finish, the status word carries MPPI_STATUS_REF_END, and the rewards are those of the
+    last row."""
+    from trajopt_amd.device import DeviceModel, DevicePlanner
     H, T, K = 4, 9, 64
-    acts, rew = got[:K * H * 7].reshape(K, H, 7), got[K * H * 7:].reshape(K, H)
     ref = np.cumsum(np.ones((T, 3)) * 0.01, axis=0)
+    monkeypatch.setenv("MPPI_NO_HOST_REF_CHECK", "1")
+    p = DevicePlanner(DeviceModel.get("reacher_7dof"), K, H, kappa=25.0, sigma=np.ones(7), betas=(0.25, 0.8, 0.0),
+                      default_act="mean", reward_type="tracking", dtype="f64", dump=True)
+    q = None
+    try:
+        p.set_params(25.0, 1.0, "tracking")
+        p.set_reference(ref, 1.0)
+        p.set_base_actions(np.zeros((H, 7)))
+        p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - H - 1)
+        p.generate_noise(1)
+        p.rollout()
+        assert p.status() & 4 == 0, "a rollout that fits must not set the bit"
+        p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - H + 1)        # indices 7, 8, 9, 10 of 9 rows
+        p.rollout()
+        assert p.status() & 4 == 4, p.status()
+        acts, rew = p.actions(), p.rewards()
+        q = DevicePlanner(DeviceModel.get("reacher_7dof"), 8, H, default_act="mean", reward_type="tracking", dtype="f64")
+        q.set_params(1.0, 1.0, "tracking")
+        q.set_reference(ref, 1.0)
+        q.set_base_actions(np.zeros((H, 7)))
+        q.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), T - 1)            # the real env would read row 9
+        q.advance()
+        q.synchronize()
+        assert q.status() & 4 == 4, q.status()
+    finally:
+        p.close()
+        if q is not None:
+            q.close()
     padded = np.concatenate([ref, np.repeat(ref[-1:], 4, axis=0)])
     _, _, rew_o = oracle_sim.rollout(np.zeros(7), np.zeros(7), np.zeros(3), T - H + 1, acts, "tracking", padded, 1.0, dump=True)
     assert np.abs(rew - rew_o).max() < 1e-9

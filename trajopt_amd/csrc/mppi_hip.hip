@@ -369,9 +369,10 @@ static int host_view(const double* src, size_t n, std::vector<double>& tmp, cons
 // device-resident advances)
 static int reference_covers(const mppi_planner* p, int steps) {
     if (p->cfg.reward_type != REWARD_TRACKING && p->cfg.reward_type != REWARD_COOLING) return 0;
-    // (test hook: with MPPI_NO_HOST_REF_CHECK=1 the kernels' own report, MPPI_STATUS_REF_END, can be observed)
-    static const bool skip = [] { const char* e = getenv("MPPI_NO_HOST_REF_CHECK"); return e && e[0] == '1'; }();
-    if (skip) return 0;
+    // (test hook, looked up at every call: with MPPI_NO_HOST_REF_CHECK=1 the kernels' own report,
+    // MPPI_STATUS_REF_END, can be observed)
+    const char* e = getenv("MPPI_NO_HOST_REF_CHECK");
+    if (e && e[0] == '1') return 0;
     for (int b = 0; b < p->P; b++) {
         const DevState& st = (*p->h_state)[b];
         if (st.ref_len > 0 && st.timestep + steps >= st.ref_len)

@@ -10,7 +10,8 @@ device and enqueued on one stream without host synchronisation: Philox noise + f
 K x H rollouts with fused reward / discounted return, max / weights / weighted action sum
 (N > 1: this shard's statistics, one RCCL all-gather of 3 + H*M doubles per rank made by the library,
 rank-ordered merge), the single fp64 step of the real environment from the planner's own state, and
-the horizon shift.  A step is one `mppi_plan` call, the replay of one captured hipGraph.  After the
+the horizon shift.  The timed steps are one `mppi_plan` call, which replays a captured hipGraph of eight
+consecutive steps (the kernels read the time step from the device-resident state).  After the
 timed region the same steps are launched piece by piece with HIP events around every rollout
 kernel (roofline.kernel_ms), and -- one GPU only -- the other flavours of the step are timed and
 reported as extra keys: the step with numpy noise uploaded from the host (`host_noise`) and the
@@ -300,9 +301,9 @@ def main():
             part = p.partials_tensor()
             gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
 
-    # Every step is one mppi_plan call: noise (drawn ahead in the previous step's advance launch), rollouts, update
-    # (sharded: statistics, all-gather, merge), real-env fp64 step, horizon shift -- a replay of one captured
-    # hipGraph.  A graph replay cannot be timed from inside: after the timed region the same steps are launched piece
+    # Every step: noise (drawn ahead in the previous step's advance launch), rollouts, update (sharded: statistics,
+    # all-gather, merge), real-env fp64 step, horizon shift; mppi_plan replays them from a captured hipGraph, eight
+    # steps per replay when asked for a run of steps.  A graph replay cannot be timed from inside: after the timed region the same steps are launched piece
     # by piece with HIP events around every rollout kernel (roofline.kernel_ms).
     EVENT_PASS_STEPS = 64
 
@@ -354,12 +355,18 @@ def main():
             gathered = torch.empty(world * part.numel(), dtype=torch.float64, device="cuda")
     if torch_exchange:
         p.generate_noise_step(SEED, sptr)
-    for i in range(args.warmup):
-        planning_step(i)
+    def planning_steps(n):
+        # a run of steps is one library call: mppi_plan replays its captured step, eight steps per replay
+        if not torch_exchange:
+            p.plan(SEED, 1, n, sptr)
+        else:
+            for i in range(n):
+                planning_step(i)
+
+    planning_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        planning_step(i)
+    planning_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     log = p.read_log(args.steps + args.warmup)

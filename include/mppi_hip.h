@@ -226,6 +226,8 @@ int mppi_advance(mppi_planner* p, void* stream);
 /* nsteps whole planning steps -- the loop `for t: agent.train_step(niter)` of the example scripts
  * (sandbox/examples/reacher_7dof_mppi.py:49-50) -- enqueued as replays of one captured hipGraph:
  * Philox noise keyed by seed + timestep, niter x (rollouts, update), device-resident advance.
+ * A call for eight steps or more replays a graph of eight consecutive steps (the kernels read the
+ * time step from the device-resident state, so one capture serves every step); same results.
  * Nothing returns to the host until mppi_read_log / mppi_read.  On handles of up to 32768 samples the
  * noise of step t+1 is drawn in the advance launch of step t (see mppi_advance_noise); afterwards the
  * noise buffer (MPPI_READ_ACTIONS) therefore belongs to the step that has not been planned yet. */

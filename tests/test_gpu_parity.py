@@ -472,8 +472,11 @@ def test_constraint_free_arm(dtype):
     assert int(np.argmax(R)) == int(np.argmax(R_o))
 
 
-def test_whole_step_graph_equals_separate_calls(dev_model):
-    K, H, steps, niter = 128, 8, 6, 3
+@pytest.mark.parametrize("steps", [6, 19])
+def test_whole_step_graph_equals_separate_calls(dev_model, steps):
+    """mppi_plan against the same steps call by call, bit for bit; 19 steps = two replays of the eight-step graph and
+    three of the one-step graph."""
+    K, H, niter = 128, 8, 3
     tgt = np.array([0.0, 0.05, 0.05])
     a = _planner(dev_model, K, H, "f32")
     b = _planner(dev_model, K, H, "f32")

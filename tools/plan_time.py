@@ -23,3 +23,10 @@ for mode in ("graph", "calls", "graph"):
     torch.cuda.synchronize()
     print(mode, (time.perf_counter() - t0) / n * 1e3, "ms/step")
 t0 = time.perf_counter(); p.plan(2024, 1, 300, s); torch.cuda.synchronize(); print("one call, 300 steps", (time.perf_counter() - t0) / 300 * 1e3)
+# runs of eight steps per replay (a call that asks for at least eight steps) against one step per replay
+for label, chunk in (("300 steps, one call (8 per replay)", 300), ("300 steps, 1 per call", 1), ("300 steps, one call (8 per replay)", 300)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300 // chunk): p.plan(2024, 1, chunk, s)
+    torch.cuda.synchronize()
+    print(label, (time.perf_counter() - t0) / 300 * 1e3, "ms/step")

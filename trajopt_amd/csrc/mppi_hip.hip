@@ -325,6 +325,7 @@ struct mppi_planner {
     hipGraphExec_t graph;           // one iteration: rollouts -> update
     uint64_t graph_gen;             // 0: never captured
     hipGraphExec_t step_graph;      // whole planning step: noise -> niter x (rollout, update) -> advance
+    hipGraphExec_t step_graph_run;  // PLAN_RUN consecutive planning steps as one graph (made when a call asks for that many)
     uint64_t step_graph_gen;
     int step_graph_niter;
     uint64_t step_graph_seed;
@@ -514,6 +515,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     delete p->h_state;
     if (p->graph) (void)hipGraphExecDestroy(p->graph);
     if (p->step_graph) (void)hipGraphExecDestroy(p->step_graph);
+    if (p->step_graph_run) (void)hipGraphExecDestroy(p->step_graph_run);
     if (p->comm) {
         std::string why;
         if (const RcclApi* api = rccl_api(why)) (void)api->CommDestroy(p->comm);
@@ -1023,6 +1025,28 @@ static int enqueue_plan_noise(mppi_planner* p, uint64_t seed, hipStream_t s) {
     return 0;
 }
 
+// `steps` consecutive planning steps captured on the planner's stream and instantiated
+constexpr int PLAN_RUN = 8;
+static int capture_steps(mppi_planner* p, uint64_t seed, int niter, int steps, bool ahead, hipGraphExec_t* out) {
+    hipGraph_t g = nullptr;
+    HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int i = 0; i < steps && !rc; i++) {
+        rc = ahead ? 0 : enqueue_plan_noise(p, seed, p->stream);
+        if (!rc) rc = enqueue_plan_body(p, seed, niter, p->stream);
+    }
+    hipError_t e = hipStreamEndCapture(p->stream, &g);
+    if (rc) {
+        if (e == hipSuccess && g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    HIP_OK(e);
+    e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIP_OK(e);
+    return 0;
+}
+
 int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, void* stream) try {
     if (!p || niter < 1 || nsteps < 0) return fail(-1, "bad argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_plan");
@@ -1048,26 +1072,25 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
     } else {
         if (!p->step_graph || p->step_graph_gen != p->cfg_gen || p->step_graph_niter != niter || p->step_graph_seed != seed) {
             if (p->step_graph) { HIP_OK(hipGraphExecDestroy(p->step_graph)); p->step_graph = nullptr; }
+            if (p->step_graph_run) { HIP_OK(hipGraphExecDestroy(p->step_graph_run)); p->step_graph_run = nullptr; }
             p->step_graph_gen = 0;
-            hipGraph_t g = nullptr;
-            HIP_OK(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-            int rc = ahead ? 0 : enqueue_plan_noise(p, seed, p->stream);
-            if (!rc) rc = enqueue_plan_body(p, seed, niter, p->stream);
-            hipError_t e = hipStreamEndCapture(p->stream, &g);
-            if (rc) {
-                if (e == hipSuccess && g) (void)hipGraphDestroy(g);
-                return rc;
-            }
-            HIP_OK(e);
-            e = hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            HIP_OK(e);
+            const int rc = capture_steps(p, seed, niter, 1, ahead, &p->step_graph);
+            if (rc) return rc;
             p->step_graph_gen = p->cfg_gen;
             p->step_graph_niter = niter;
             p->step_graph_seed = seed;
         }
+        // A run of steps is replayed PLAN_RUN at a time: the kernels take the time step from the device-resident state,
+        // so the same launches serve every step, and the boundary between two replays costs the stream more than the
+        // boundary between two kernels of one replay.
+        if (nsteps >= PLAN_RUN && !p->step_graph_run) {
+            const int rc = capture_steps(p, seed, niter, PLAN_RUN, ahead, &p->step_graph_run);
+            if (rc) return rc;
+        }
         if (ahead && !have_noise) { const int rc = enqueue_plan_noise(p, seed, s); if (rc) return rc; }
-        for (int i = 0; i < nsteps; i++) HIP_OK(hipGraphLaunch(p->step_graph, s));
+        int left = nsteps;
+        for (; left >= PLAN_RUN; left -= PLAN_RUN) HIP_OK(hipGraphLaunch(p->step_graph_run, s));
+        for (; left > 0; left--) HIP_OK(hipGraphLaunch(p->step_graph, s));
     }
     p->noise_ahead = ahead;
     p->noise_ahead_seed = seed;

@@ -42,8 +42,16 @@ __global__ void __launch_bounds__(64) c_build_rows(const float* in, float* out) 
     static_for<NV>([&](auto I) { q[I] = IN(3 * NV + I); fr.cs(I) = IN(I); fr.sn(I) = IN(NV + I); qd[I] = IN(2 * NV + I); });
     typename S::Rows r;
     S::build_rows(q, fr, qd, r);
-    static_for<NV>([&](auto I) { OUT(I) = r.Dl[I / 2][I % 2]; OUT(NV + I) = r.sal[I / 2][I % 2]; OUT(2 * NV + I) = r.xs[I / 2][I % 2]; OUT(3 * NV + I) = r.Jc[I]; });
-    OUT(4 * NV) = r.Dc + r.arc;
+    typename S::ContactProbe pr;
+    const bool wave = S::contact_probe(q, fr, pr);
+    static_for<NV>([&](auto I) { OUT(I) = r.Dl[I / 2][I % 2]; OUT(NV + I) = r.sal[I / 2][I % 2]; OUT(2 * NV + I) = r.xs[I / 2][I % 2]; });
+    OUT(4 * NV) = pr.dist;
+    if (wave) {
+        typename S::ContactRow cr;
+        S::contact_row(fr, qd, pr, cr);
+        static_for<NV>([&](auto I) { OUT(3 * NV + I) = cr.Jc[I]; });
+        OUT(4 * NV + 1) = cr.Dc + cr.arc;
+    }
 }
 __global__ void __launch_bounds__(64) c_hand_site(const float* in, float* out) {
     float q[NV];

@@ -317,8 +317,16 @@ template <class T, class MD> struct Step {
     static constexpr int NP = (NV + 1) / 2;
     struct Rows {
         Pair<T> Dl[NP], sal[NP], xs[NP];   // limit rows: weight (0 = no row), reference acceleration of the joint, signed violation
-        T Jc[NV], Dc, arc;                 // contact row: Jacobian, weight (0 = no row), reference acceleration
     };
+    // The contact row is made in two steps: every substep measures the distance of the sphere from the plane
+    // (ContactProbe); the row itself -- Jacobian, weight, reference acceleration -- is only made in a substep in which
+    // some sample of the wave is within the margin, inside the variant of the solve that has a contact row.
+    struct ContactProbe {
+        Vec3<T> xc[NV];                    // the sphere's centre in the coordinates of every link on the way to the world
+        T dist;                            // distance of the sphere from the plane
+        Mask<T> near;                      // within the margin: this sample has the row
+    };
+    struct ContactRow { T Jc[NV], Dc, arc; };      // Jacobian, weight (0 = no row), reference acceleration
     // Which rows ended the previous substep inactive: the
     // weight such a row was not given, > 0 only for a row that existed and was inactive.  Carried through a
     // rollout as the starting guess of the active-set solve; every other row, the ones that did not exist
@@ -423,38 +431,48 @@ template <class T, class MD> struct Step {
                 });
             }
         });
+    }
+
+    // distance of the contact sphere from the plane; true if some sample of the wave is within the margin
+    static MPPI_HD bool contact_probe(const T (&q)[NQ], const Frames& fr, ContactProbe& c) {
+        if constexpr (MD::contact_link >= 0) {
+            constexpr int L = MD::contact_link;
+            const Vec3<T> cw = point_to_world<L>(q, fr, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, c.xc);
+            c.dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
+            c.near = c.dist < T(MD::contact_margin);
+            return wave_any(c.near);       // uniform over the wave
+        } else {
+            return false;
+        }
+    }
+    // the contact row of the samples within the margin; the others get zeros
+    static MPPI_HD void contact_row(const Frames& fr, const T (&qd)[NV], const ContactProbe& c, ContactRow& r) {
         r.Dc = T(0); r.arc = T(0);
         static_for<NV>([&](auto Ic) { r.Jc[Ic] = T(0); });
         if constexpr (MD::contact_link >= 0) {
             constexpr int L = MD::contact_link;
-            Vec3<T> xc[NV];
-            const Vec3<T> cw = point_to_world<L>(q, fr, {{T(MD::contact_pos[0]), T(MD::contact_pos[1]), T(MD::contact_pos[2])}}, xc);
-            const T dist = cw.v[2] - T(MD::contact_radius) - T(MD::contact_plane_z);
-            const Mask<T> near = dist < T(MD::contact_margin);
-            if (MPPI_UNLIKELY(wave_any(near))) {       // uniform over the wave; lanes away from the plane get zeros
-                // d(z of the sphere centre)/dq_i = z_i . (axis_i x x_i): world z axis and the point, both in link-i coordinates
-                Vec3<T> zl[NV];
-                T vel = T(0);
-                static_for<NV>([&](auto Ic) {
-                    constexpr int i = Ic;
-                    if constexpr (on_path(i, L)) {
-                        static_assert(MD::jtype[i] == 0, "the contact row is written for hinge chains");
-                        constexpr int p = MD::parent[i];
-                        constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
-                        Vec3<T> zp;
-                        if constexpr (p < 0) zp = {{T(0), T(0), T(1)}};
-                        else zp = zl[p];
-                        zl[i] = down<i>(fr, zp);
-                        // (e_A x x)[U] = -x[W], (e_A x x)[W] = x[U]
-                        r.Jc[i] = sel(near, T(MD::axis_sign[i]) * (zl[i].v[W] * xc[i].v[U] - zl[i].v[U] * xc[i].v[W]), T(0));
-                        vel += r.Jc[i] * qd[i];
-                    }
-                });
-                T Dc, arc;
-                row_constants(dist - T(MD::contact_margin), T(MD::solref_b) * vel, T(MD::contact_invweight), Dc, arc);
-                r.Dc = sel(near, Dc, T(0));
-                r.arc = sel(near, arc, T(0));
-            }
+            // d(z of the sphere centre)/dq_i = z_i . (axis_i x x_i): world z axis and the point, both in link-i coordinates
+            Vec3<T> zl[NV];
+            T vel = T(0);
+            static_for<NV>([&](auto Ic) {
+                constexpr int i = Ic;
+                if constexpr (on_path(i, L)) {
+                    static_assert(MD::jtype[i] == 0, "the contact row is written for hinge chains");
+                    constexpr int p = MD::parent[i];
+                    constexpr int A = MD::axis_id[i], U = (A + 1) % 3, W = (A + 2) % 3;
+                    Vec3<T> zp;
+                    if constexpr (p < 0) zp = {{T(0), T(0), T(1)}};
+                    else zp = zl[p];
+                    zl[i] = down<i>(fr, zp);
+                    // (e_A x x)[U] = -x[W], (e_A x x)[W] = x[U]
+                    r.Jc[i] = sel(c.near, T(MD::axis_sign[i]) * (zl[i].v[W] * c.xc[i].v[U] - zl[i].v[U] * c.xc[i].v[W]), T(0));
+                    vel += r.Jc[i] * qd[i];
+                }
+            });
+            T Dc, arc;
+            row_constants(c.dist - T(MD::contact_margin), T(MD::solref_b) * vel, T(MD::contact_invweight), Dc, arc);
+            r.Dc = sel(c.near, Dc, T(0));
+            r.arc = sel(c.near, arc, T(0));
         }
     }
 
@@ -495,8 +513,11 @@ template <class T, class MD> struct Step {
     // until every lane has settled, so the only cross-lane operation is one vote per sweep.  A model with rows
     // always runs the first sweep, also in the rare substep in which no lane of the wave has a row (all weights
     // zero then: the sweep is the unconstrained solve): a test for that case is a branch on every substep.
+    //   contact_wave / probe : whether some sample of the wave is within the contact margin in this substep, and the
+    //              measurements its row is made from (contact_probe)
     static MPPI_HD void constraint_forces(const T (&M)[NV][NV], const T (&fs)[NV], const Rows& r, Active& act,
-                                          T (&ftot)[NV], int& sweeps_out, DampedFactor& damped) {
+                                          T (&ftot)[NV], int& sweeps_out, DampedFactor& damped, const Frames& fr,
+                                          const T (&qd)[NV], bool contact_wave, const ContactProbe& probe) {
         if constexpr (!has_rows()) {
             static_for<NV>([&](auto Ic) { ftot[Ic] = fs[Ic]; });
             factor_damped(M, damped);
@@ -505,7 +526,7 @@ template <class T, class MD> struct Step {
             int sweeps = 0;
             // active weight of every row: its D while active, 0 while inactive or absent
             Pair<T> dgp[NP];
-            T dc = sel(act.idle_contact > T(0), T(0), r.Dc);
+            T idle_contact = T(0);      // weight withheld from the contact row at the end of this substep
             static_for<NP>([&](auto Pc) {
                 dgp[Pc] = make_pair_of(sel(act.idle[Pc][0] > T(0), T(0), r.Dl[Pc][0]), sel(act.idle[Pc][1] > T(0), T(0), r.Dl[Pc][1]));
             });
@@ -522,6 +543,13 @@ template <class T, class MD> struct Step {
             // branch costs a lone wave about as much as a dozen vector instructions
             auto sweep_all = [&](auto Wc) {
                 constexpr bool WC = decltype(Wc)::value;
+                // the contact row exists in this variant only (without it: fields nothing reads)
+                ContactRow cr;
+                T dc = T(0);
+                if constexpr (WC) {
+                    contact_row(fr, qd, probe, cr);
+                    dc = sel(act.idle_contact > T(0), T(0), cr.Dc);
+                }
                 // residual signs decide the next active set; true if this lane's set changed.  Grow: rows may join the
                 // set but not leave it (the late sweeps of a solve that keeps changing, see below).
                 auto settle = [&](auto Grow) -> Mask<T> {
@@ -543,9 +571,9 @@ template <class T, class MD> struct Step {
                     });
                     if constexpr (WC) {
                         T ja = T(0);
-                        static_for<NV>([&](auto Ic) { ja += r.Jc[Ic] * acc[Ic]; });
-                        resc = ja - r.arc;
-                        const T nd = sel(resc < T(0), r.Dc, GROW ? dc : T(0));
+                        static_for<NV>([&](auto Ic) { ja += cr.Jc[Ic] * acc[Ic]; });
+                        resc = ja - cr.arc;
+                        const T nd = sel(resc < T(0), cr.Dc, GROW ? dc : T(0));
                         MPPI_SWEEP_TRACE(sweeps, NV, nd != dc);
                         changed |= (nd != dc);
                         dc = nd;
@@ -559,18 +587,18 @@ template <class T, class MD> struct Step {
                         acc[2 * Pc] = b[0]; dg[2 * Pc] = dgp[Pc][0];
                         if constexpr (2 * Pc + 1 < NV) { acc[2 * Pc + 1] = b[1]; dg[2 * Pc + 1] = dgp[Pc][1]; }
                     });
-                    if constexpr (WC) static_for<NV>([&](auto Ic) { acc[Ic] += dc * r.arc * r.Jc[Ic]; });
+                    if constexpr (WC) static_for<NV>([&](auto Ic) { acc[Ic] += dc * cr.arc * cr.Jc[Ic]; });
                 };
                 sweeps = 1;
                 right_hand_side();
-                dual_factor<WC, true>(M, dg, WC ? dc : T(0), r.Jc, acc, hb, damped.D, damped.inv);
+                dual_factor<WC, true>(M, dg, WC ? dc : T(0), cr.Jc, acc, hb, damped.D, damped.inv);
                 Mask<T> changed = settle(std::false_type{});
                 // Among the 64 samples of a wave one nearly always moves a row (a limit row released by a new torque,
                 // a joint arriving at its limit), so the second sweep is laid out as the fall-through path.
                 if (MPPI_LIKELY(wave_any(changed))) {
                     sweeps = 2;
                     right_hand_side();
-                    chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                    chol_solve<WC>(M, dg, WC ? dc : T(0), cr.Jc, acc);
                     changed = settle(std::false_type{});
                     // Rows join and leave the set freely for the first FREE sweeps, which settles all but a few
                     // solves in a million.  The rest are rows whose residual is zero to rounding and whose sign
@@ -583,7 +611,7 @@ template <class T, class MD> struct Step {
                         while (sweeps < free_end) {
                             sweeps++;
                             right_hand_side();
-                            chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                            chol_solve<WC>(M, dg, WC ? dc : T(0), cr.Jc, acc);
                             changed = settle(std::false_type{});
                             if (!wave_any(changed)) break;
                         }
@@ -591,7 +619,7 @@ template <class T, class MD> struct Step {
                             while (sweeps < act.cap) {
                                 sweeps++;
                                 right_hand_side();
-                                chol_solve<WC>(M, dg, WC ? dc : T(0), r.Jc, acc);
+                                chol_solve<WC>(M, dg, WC ? dc : T(0), cr.Jc, acc);
                                 changed = settle(std::true_type{});
                                 if (!wave_any(changed)) break;
                             }
@@ -607,18 +635,19 @@ template <class T, class MD> struct Step {
                 });
                 if constexpr (WC) {
                     const T f = -dc * resc;
-                    static_for<NV>([&](auto Ic) { ftot[Ic] += r.Jc[Ic] * f; });
+                    static_for<NV>([&](auto Ic) { ftot[Ic] += cr.Jc[Ic] * f; });
+                    idle_contact = cr.Dc - dc;
                 }
             };
             if constexpr (MD::contact_link >= 0) {
-                if (MPPI_UNLIKELY(wave_any(r.Dc > T(0)))) sweep_all(std::true_type{});
+                if (MPPI_UNLIKELY(contact_wave)) sweep_all(std::true_type{});
                 else sweep_all(std::false_type{});
             } else {
                 sweep_all(std::false_type{});
             }
             // the weight withheld from every row: positive for the inactive ones, zero for active and absent rows
             static_for<NP>([&](auto Pc) { act.idle[Pc] = r.Dl[Pc] - dgp[Pc]; });
-            act.idle_contact = r.Dc - dc;
+            act.idle_contact = idle_contact;
             sweeps_out = sweeps;
         }
     }
@@ -667,8 +696,10 @@ template <class T, class MD> struct Step {
         mass_matrix(q, fr, M);
         Rows rows;
         build_rows(q, fr, qd, rows);
+        ContactProbe probe;
+        const bool contact_wave = contact_probe(q, fr, probe);
         DampedFactor f;
-        constraint_forces(M, fs, rows, act, qacc, sweeps_out, f);
+        constraint_forces(M, fs, rows, act, qacc, sweeps_out, f, fr, qd, contact_wave, probe);
         if constexpr (LEAF_FIRST) leaf_first_apply(f.L, f.inv, qacc);
         else if constexpr (DUAL) dual_apply(f.D, f.inv, qacc);
         else chol_apply(f.P, f.inv, qacc);

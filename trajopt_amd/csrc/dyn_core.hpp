@@ -184,6 +184,15 @@ template <class E> MPPI_HD Vec3<E> add(const Vec3<E>& a, const Vec3<E>& b) {
     return {{a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2]}};
 }
 template <class T, class E> MPPI_HD Vec3<E> scale(T s, const Vec3<E>& a) { return {{s * a.v[0], s * a.v[1], s * a.v[2]}}; }
+// dst[1] += r x src[0] for a vector of pairs (the moment of a force about a displaced origin added to the moment half):
+// written as packed multiply-adds of {0, r_k} with the force half broadcast, so that the pair is updated as a pair
+template <class T> MPPI_HD void add_cross_to_second(Vec3<Pair<T>>& dst, const Vec3<T>& r, const Vec3<Pair<T>>& src) {
+    const Pair<T> r0 = make_pair_of(T(0), r.v[0]), r1 = make_pair_of(T(0), r.v[1]), r2 = make_pair_of(T(0), r.v[2]);
+    const Pair<T> s0 = splat_half<0>(src.v[0]), s1 = splat_half<0>(src.v[1]), s2 = splat_half<0>(src.v[2]);
+    dst.v[0] += r1 * s2 - r2 * s1;
+    dst.v[1] += r2 * s0 - r0 * s2;
+    dst.v[2] += r0 * s1 - r1 * s0;
+}
 
 // rotation about coordinate axis A by angle (c, s): parent coordinates from child coordinates
 template <int A, class T, class E> MPPI_HD Vec3<E> to_parent(T c, T s, const Vec3<E>& x) {
@@ -793,6 +802,18 @@ template <class T, class MD> struct Step {
                 const Vec3<T> da = cross(wcar, sq);
                 static_for<3>([&](auto Cn) { l.v[Cn][1] += da.v[Cn]; });
                 l.v[A][0] += sq.v[A];
+            } else if constexpr (MD::jtype[i] == 0) {
+                // hinge: V x (s e_A) has the components +s V_W (at U) and -s V_U (at W); it goes into the acceleration
+                // halves as one packed multiply-add per component, {0, s} times the velocity half of the other
+                // component (the velocity halves receive + 0)
+                constexpr int U = (A + 1) % 3, W = (A + 2) % 3;
+                const P sp = make_pair_of(T(0), sq.v[A]);
+                const P aU = a.v[U], lU = l.v[U];
+                a.v[U] = aU + sp * splat_half<0>(a.v[W]);
+                a.v[W] = a.v[W] - sp * splat_half<0>(aU);
+                l.v[U] = lU + sp * splat_half<0>(l.v[W]);
+                l.v[W] = l.v[W] - sp * splat_half<0>(lU);
+                a.v[A][0] += sq.v[A];
             } else {
                 const Vec3<T> dw = cross(wcar, sq), dv = cross(vcar, sq);
                 static_for<3>([&](auto Cn) { a.v[Cn][1] += dw.v[Cn]; l.v[Cn][1] += dv.v[Cn]; });
@@ -926,8 +947,7 @@ template <class T, class MD> struct Step {
             constexpr int A = MD::axis_id[I];
             const Vec3<T> r = off_<I>(q);
             Vec3<Pair<T>> par = up<I>(fr, fm);
-            const Vec3<T> rf = cross(r, half<T>(par, 0));
-            static_for<3>([&](auto Cn) { par.v[Cn][1] += rf.v[Cn]; });
+            add_cross_to_second(par, r, par);
             M[COL][p] = T(MD::axis_sign[p]) * par.v[MD::axis_id[p]][MD::jtype[p] == 1 ? 0 : 1];
             walk_up<COL, p>(q, fr, par, M);
         }

@@ -807,7 +807,9 @@ template <class T, class MD> struct Step {
                 // halves as one packed multiply-add per component, {0, s} times the velocity half of the other
                 // component (the velocity halves receive + 0)
                 constexpr int U = (A + 1) % 3, W = (A + 2) % 3;
-                const P sp = make_pair_of(T(0), T(MD::axis_sign[i])) * qd[i];     // {0, s} in one packed multiply
+                // ({0, s} by one packed multiply of a constant pair saves the zero's register copy and costs a lone
+                // wave more than it saves: one more link in the dependent chain of every joint)
+                const P sp = make_pair_of(T(0), sq.v[A]);
                 const P aU = a.v[U], lU = l.v[U];
                 a.v[U] = aU + sp * splat_half<0>(a.v[W]);
                 a.v[W] = a.v[W] - sp * splat_half<0>(aU);

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define MPPI_MAXV 32
-#define MPPI_ABI_VERSION 7
+#define MPPI_ABI_VERSION 8
 #define MPPI_LOG_CAP 4096
 #define MPPI_NOALLOC_MAX_K 262144   /* most samples mppi_update_from_returns_noalloc accepts */
 
@@ -153,6 +153,12 @@ int mppi_set_base_actions(mppi_planner* p, const double* act_HxM);
  * ref may be NULL with T = 0. */
 int mppi_set_reference(mppi_planner* p, const double* ref_Tx3, int32_t T, double alpha);
 int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_type);
+/* Reward the planner's own step of the real environment reports (mppi_advance, mppi_plan: `self.env.step` of
+ * `MPPI.advance_time`, trajopt/algos/mppi.py:79) when that environment was built with another `reward_type` than the
+ * rollouts are scored with (trajopt/envs/utils.py:8, trajopt/algos/mppi.py:117: the actor-critic scripts plan on
+ * 'cooling' and log the 'sparse' reward).  MPPI_REWARD_* or -1 (the default): the rollouts' own.  A tracking or cooling
+ * reward reads the reference of mppi_set_reference at time step + 1; -5 from the advancing calls past its end. */
+int mppi_set_env_reward(mppi_planner* p, int32_t reward_type);
 /* Terminal-value critic of `MPPI.train_step(critic=...)` (trajopt/algos/mppi.py:134-159, 95-101;
  * network trajopt/models/critic_nets.py:47-60): tanh MLP dim -> inner -> inner -> 1 in fp32, row-major
  * weights as torch stores them (W1 [inner][dim], W2 [inner][inner], W3 [inner]).  While set, every

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert L.mppi_version() == 7
+    assert L.mppi_version() == 8
 
 
 def test_struct_layouts_match_the_header():

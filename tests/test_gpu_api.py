@@ -234,20 +234,26 @@ def test_train_step_follows_what_the_caller_changes_between_steps(oracle_sim):
     assert len(ag.sol_act) == 14 and np.all(np.array(ag.sol_act)[:10] == 0) and np.any(ag.sol_act[12] != 0)
 
 
-@pytest.mark.parametrize("noise", ["philox", "host"])
-def test_resident_train_step_equals_the_step_by_step_one(noise):
+@pytest.mark.parametrize("noise,rewards", [("philox", ("dense", "dense")), ("host", ("dense", "dense")),
+                                           ("philox", ("sparse", "cooling")), ("host", ("tracking", "cooling"))])
+def test_resident_train_step_equals_the_step_by_step_one(noise, rewards):
     """The device-resident step (state, act_sequence and the real environment's step stay on the device) against the
     same planner driven piece by piece with everything sent again at every call (`advance_time` on the host side, which
     an `act_sequence=` argument asks for): same trajectory, bit for bit in fp64."""
     from trajopt.algos.mppi import MPPI
     from trajopt.envs.utils import get_environment
     goal = (0.05, 0.0, 0.05)
+    # the environment's own reward need not be the one the rollouts are scored with (the actor-critic scripts log the
+    # sparse reward of rollouts scored with 'cooling'): the device's step reports the environment's
+    env_reward, rollout_reward = rewards
+    ref = np.array([[0.2 - 0.01 * t, 0.1, 0.3 - 0.01 * t] for t in range(40)])
     logs = []
     for resident in (True, False):
-        e = get_environment('reacher_7dof')
-        e.reset_model(seed=2, goal=goal)
+        e = get_environment('reacher_7dof', reward_type=env_reward, reference=ref if env_reward == "tracking" else None)
+        e.reset_model(seed=2, goal=goal, alpha=0.7)
         ag = MPPI(e, H=10, paths_per_cpu=64, kappa=25.0, filter_coefs=FILTER, default_act='repeat', seed=4, noise=noise,
-                  dtype="f64")
+                  dtype="f64", reward_type=rollout_reward, reference=ref if rollout_reward != "dense" else None)
+        assert ag._real_env_steps_on_the_device()
         for step in range(6):
             if resident:
                 ag.train_step(niter=2)

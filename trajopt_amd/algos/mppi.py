@@ -157,7 +157,7 @@ class MPPI(Trajectory):
         t = len(self.sol_state) - 1
         weights = _critic_weights(critic, dim)
         if self.env.env_name in _KERNEL_ENVS and (critic is None or weights is not None):
-            if act_sequence is None and self._real_env_steps_like_the_rollouts():
+            if act_sequence is None and self._real_env_steps_on_the_device():
                 # the whole step, the real environment's included, without leaving the device
                 self._plan_on_device(self.seed + t, niter, dim if critic is not None else 0, weights, advance=True)
                 return []
@@ -172,23 +172,26 @@ class MPPI(Trajectory):
         return []
 
     # ---- device-resident iteration ------------------------------------------------------
-    def _real_env_steps_like_the_rollouts(self):
+    def _real_env_steps_on_the_device(self):
         """True if the device planner's own fp64 step of the real environment is what `self.env.step` would do: a
-        plain reacher whose reward is the one the rollouts are scored with (the planner logs that reward)."""
+        plain reacher, scored with its own reward type (the planner is told which: it need not be the one the rollouts
+        are scored with -- the actor-critic scripts plan on 'cooling' and log 'sparse').  An environment that tracks a
+        reference must track the one the rollouts use: the device holds one."""
         from ..envs.reacher_env import Reacher7DOFEnv
         e = self.env
         if type(e) is not Reacher7DOFEnv:
             return False
         rt, reference = rollout_objective(e.env_name, self.reward_type, self.reference)
-        rt_env = e.reward_type if e.reward_type in ('sparse', 'tracking', 'cooling') else 'dense'
-        if rt != rt_env:
-            return False
-        if rt in ('tracking', 'cooling'):
-            if e.reference is None or reference is None:
+        if self._env_reward() in ('tracking', 'cooling'):
+            if rt not in ('tracking', 'cooling') or e.reference is None or reference is None:
                 return False
             if e.reference is not reference and not np.array_equal(np.asarray(e.reference), np.asarray(reference)):
                 return False
         return True
+
+    def _env_reward(self):
+        rt = self.env.reward_type
+        return rt if rt in ('sparse', 'tracking', 'cooling') else 'dense'
 
     def _device_holds(self, p, s):
         d = self._dev_state
@@ -217,6 +220,8 @@ class MPPI(Trajectory):
             p.set_base_actions(self.act_sequence)
         self._dev_state = self._dev_seq = None           # until the outcome of this step has been read back
         p.set_critic(critic_dim, critic_weights)         # a no-op while dim and weights stay what they were
+        if advance:
+            p.set_env_reward(self._env_reward())
         if self.noise == 'philox':
             if advance:
                 # the device keys its stream with seed argument + time step of its state; one launch of the captured step

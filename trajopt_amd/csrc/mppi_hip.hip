@@ -307,6 +307,7 @@ struct mppi_planner {
     void* d_fobs;          // T [K][2M+6] final observation of every sample (critic input)
     float* d_critic;       // packed critic weights (CRITIC_W_FLOATS) or null
     int critic_dim;        // 0: no critic
+    int env_reward_type;   // reward the real environment's step reports (mppi_set_env_reward); -1: the rollouts' own
     double* d_log;         // [LOG_CAP][3M+7] real-env log ring of mppi_advance
     int* d_log_count;
     double* d_last_row;    // [P][3M+7] the newest log row of every planner (mppi_read_step)
@@ -365,11 +366,15 @@ static int host_view(const double* src, size_t n, std::vector<double>& tmp, cons
     return 0;
 }
 
+// reward type of the real environment's step inside mppi_advance / mppi_plan: the rollouts' own unless
+// mppi_set_env_reward chose another
+static int env_reward(const mppi_planner* p) { return p->env_reward_type >= 0 ? p->env_reward_type : p->cfg.reward_type; }
+
 // tracking / cooling rewards read reference[timestep + 1 .. timestep + steps]: the reference raises IndexError past
 // the end (trajopt/envs/reacher_env.py:61,75); -5 here, from the host's copy of the time step (kept in step with
 // device-resident advances)
-static int reference_covers(const mppi_planner* p, int steps) {
-    if (p->cfg.reward_type != REWARD_TRACKING && p->cfg.reward_type != REWARD_COOLING) return 0;
+static int reference_covers(const mppi_planner* p, int steps, int reward_type) {
+    if (reward_type != REWARD_TRACKING && reward_type != REWARD_COOLING) return 0;
     // (test hook, looked up at every call: with MPPI_NO_HOST_REF_CHECK=1 the kernels' own report,
     // MPPI_STATUS_REF_END, can be observed)
     const char* e = getenv("MPPI_NO_HOST_REF_CHECK");
@@ -490,6 +495,7 @@ int mppi_planner_create(const mppi_model* m, const mppi_planner_cfg* cfg, mppi_p
     if (p->cfg.sweep_cap == 0) p->cfg.sweep_cap = 16;
     p->esz = cfg->dtype == MPPI_F32 ? 4 : 8;
     p->cfg_gen = 1;
+    p->env_reward_type = -1;
     p->prof_events = new std::vector<hipEvent_t>();
     p->h_state = new std::vector<DevState>(p->P);
     std::memset(p->h_state->data(), 0, sizeof(DevState) * p->P);
@@ -637,6 +643,16 @@ int mppi_set_params(mppi_planner* p, double kappa, double gamma, int32_t reward_
     return fail(-8, std::string("host exception: ") + e.what());
 }
 
+int mppi_set_env_reward(mppi_planner* p, int32_t reward_type) try {
+    if (!p) return fail(-1, "null argument");
+    if (reward_type < -1 || reward_type > 3) return fail(-1, "bad reward_type");
+    if (p->env_reward_type != reward_type) p->cfg_gen++;      // the advance launch of a captured step carries it
+    p->env_reward_type = reward_type;
+    return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
+}
+
 int mppi_host_staging(mppi_planner* p, double** out) try {
     if (!p || !out) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -747,9 +763,9 @@ int mppi_advance(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance");
     HIP_OK(hipSetDevice(p->cfg.device));
-    const int rc = reference_covers(p, 1);
+    const int rc = reference_covers(p, 1, env_reward(p));
     if (rc) return rc;
-    HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
+    HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
                                   p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, pick(p, stream)));
     for (DevState& st : *p->h_state) st.timestep++;
     return 0;
@@ -761,9 +777,9 @@ int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_advance_noise");
     HIP_OK(hipSetDevice(p->cfg.device));
-    const int rc = reference_covers(p, 1);
+    const int rc = reference_covers(p, 1, env_reward(p));
     if (rc) return rc;
-    HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
+    HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P,
                                         p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
                                         p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps,
                                         p->d_noise_key, pick(p, stream)));
@@ -909,7 +925,7 @@ static int launch_merge(mppi_planner* p, const double* gathered, int nranks, hip
 int mppi_rollout(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     {
-        const int rc = reference_covers(p, p->cfg.H);
+        const int rc = reference_covers(p, p->cfg.H, p->cfg.reward_type);
         if (rc) return rc;
     }
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -922,7 +938,7 @@ int mppi_local_partials(mppi_planner* p, void* stream) try {
     if (!p) return fail(-1, "null argument");
     if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
     {
-        const int rc = reference_covers(p, p->cfg.H);
+        const int rc = reference_covers(p, p->cfg.H, p->cfg.reward_type);
         if (rc) return rc;
     }
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -975,7 +991,7 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) try {
     if (!p || niter < 0) return fail(-1, "bad argument");
     if (p->explicit_act) return fail(-4, "update needs noise-relative samples; call mppi_upload_noise or mppi_generate_noise");
     if (niter > 0) {
-        const int rc = reference_covers(p, p->cfg.H);
+        const int rc = reference_covers(p, p->cfg.H, p->cfg.reward_type);
         if (rc) return rc;
     }
     HIP_OK(hipSetDevice(p->cfg.device));
@@ -1010,12 +1026,12 @@ static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStrea
         if (rc) return rc;
     }
     if (plan_draws_ahead(p))
-        HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P,
+        HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P,
                                             p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
                                             p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps,
                                             p->d_noise_key, s));
     else
-        HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, p->cfg.reward_type, p->cfg.H, p->P, p->cfg.default_act,
+        HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P, p->cfg.default_act,
                                       p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, s));
     return 0;
 }
@@ -1052,7 +1068,8 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
     if (p->HM > 256 * 16) return fail(-1, "H*M too large for mppi_plan");
     if (nsteps == 0) return 0;
     {   // the last of the steps rolls out from time step t + nsteps - 1
-        const int rc = reference_covers(p, nsteps - 1 + p->cfg.H);
+        int rc = reference_covers(p, nsteps - 1 + p->cfg.H, p->cfg.reward_type);
+        if (!rc) rc = reference_covers(p, nsteps, env_reward(p));
         if (rc) return rc;
     }
     HIP_OK(hipSetDevice(p->cfg.device));

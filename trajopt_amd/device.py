@@ -141,6 +141,13 @@ class DevicePlanner:
     def set_params(self, kappa, gamma, reward_type):
         L.check(L.lib().mppi_set_params(self._h, float(kappa), float(gamma), L.REWARD_TYPES[reward_type]))
 
+    def set_env_reward(self, reward_type):
+        """Reward type the planner's own step of the real environment reports (None: the rollouts')."""
+        rt = -1 if reward_type is None else L.REWARD_TYPES[reward_type]
+        if rt != getattr(self, "_env_reward_sent", -1):
+            L.check(L.lib().mppi_set_env_reward(self._h, rt))
+            self._env_reward_sent = rt
+
     def set_critic(self, dim, weights=None):
         """weights = (W1, b1, W2, b2, W3, b3) as float32 arrays in torch's row-major layout, or
         None / dim 0 to remove the critic."""

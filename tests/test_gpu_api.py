@@ -17,6 +17,12 @@ def test_env_duck_type_and_transitions(transitions, oracle_sim):
     e = get_environment('reacher_7dof')
     assert e.env_name == 'reacher_7dof' and e.action_dim == 7 and e.observation_dim == 26
     assert e.env_timestep == 1                      # the constructor takes one zero-action step
+    # gym-style spaces and metadata (trajopt/envs/mujoco_env.py:45-65): control range of the seven motors, unbounded
+    # 20-dim observations, 1 / dt frames per second
+    assert e.action_space.shape == (7,) and e.action_space.dtype == np.float32 and e.observation_space.shape == (20,)
+    assert np.array_equal(e.action_space.low, e.model.actuator_ctrlrange[:, 0].astype(np.float32))
+    assert np.all(np.isinf(e.observation_space.high)) and e.action_space.contains(e.action_space.sample())
+    assert e.metadata['video.frames_per_second'] == int(np.round(1.0 / e.dt)) and e.obs_dim == 20
     ob = e.reset_model(goal=(0.05, 0.0, -0.1))
     assert e.env_timestep == 0 and ob.shape == (20,)
     assert np.allclose(ob[14:17], [0.821, -0.6, 0.0], atol=1e-12) and np.allclose(ob[17:], [0.05, 0.0, -0.1])

@@ -52,6 +52,42 @@ class _Model:
         return self._sites[name]
 
 
+class _Box:
+    """`gym.spaces.Box` look-alike (gym is not a dependency here): the bounds of `action_space` and
+    `observation_space` (trajopt/envs/mujoco_env.py:58-65), which policy-learning code reads for shapes and limits."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low = np.asarray(low, dtype=dtype)
+        self.high = np.asarray(high, dtype=dtype)
+        self.shape = self.low.shape
+        self.dtype = np.dtype(dtype)
+        self.np_random = np.random.RandomState()
+
+    def seed(self, seed=None):
+        self.np_random = np.random.RandomState(seed)
+        return [seed]
+
+    def sample(self):
+        """Uniform inside bounded dimensions, standard normal along unbounded ones."""
+        bounded = np.isfinite(self.low) & np.isfinite(self.high)
+        x = self.np_random.normal(size=self.shape)
+        u = self.np_random.uniform(size=self.shape)
+        lo, hi = np.where(bounded, self.low, 0.0), np.where(bounded, self.high, 0.0)
+        return np.where(bounded, lo + u * (hi - lo), x).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    __contains__ = contains
+
+    def __repr__(self):
+        return "Box%s" % (self.shape,)
+
+    def __eq__(self, other):
+        return isinstance(other, _Box) and np.array_equal(self.low, other.low) and np.array_equal(self.high, other.high)
+
+
 class _Sim:
     def __init__(self, env):
         self._env = env
@@ -95,6 +131,10 @@ class Reacher7DOFEnv:
         self.obs_dim = 2 * md.nv + 6
         self.mujoco_render_frames = False
         self.viewer = None
+        self.metadata = {'render.modes': ['human', 'rgb_array'],
+                         'video.frames_per_second': int(np.round(1.0 / (md.h * md.frame_skip)))}
+        self.action_space = _Box(self.model.actuator_ctrlrange[:, 0], self.model.actuator_ctrlrange[:, 1])
+        self.observation_space = _Box(-np.inf * np.ones(self.obs_dim), np.inf * np.ones(self.obs_dim))
         self.np_random = np.random.RandomState()
         self.goal_dist = np.array([0.0])
         self._ctor = dict(reward_type=reward_type, reference=reference)

@@ -247,8 +247,13 @@ int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream);
 int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
 /* What one `MPPI.train_step` hands back to its caller (trajopt/algos/mppi.py:74-89), after mppi_advance,
  * mppi_advance_noise or mppi_plan: the newest log row of every planner (P x (3M+7) doubles, layout as in
- * mppi_advance) and the shifted act_sequence (P x H*M doubles), as two copies behind the planner's stream and one
- * wait.  Either pointer may be NULL. */
+ * mppi_advance) and the shifted act_sequence (P x H*M doubles).  Either pointer may be NULL.
+ * A single planner (P = 1) whose newest step was a lone advance or a single step of mppi_plan gets them without a copy:
+ * that step's kernel also writes both, and then the count of steps logged, into page-locked host memory of the planner,
+ * and this call only waits for the count (it looks at the stream now and then, so a launch that failed cannot hang
+ * it).  Every other case (batched planners, the last step inside a multi-step replay, act_sequence changed since by
+ * mppi_set_base_actions / mppi_iterate / mppi_merge / mppi_shift) is two copies behind the stream of the last step and
+ * one wait. */
 int mppi_read_step(mppi_planner* p, double* rows_out, double* act_seq_out);
 
 int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes);

@@ -273,3 +273,55 @@ def test_log_ring_wraps_and_reads_back_in_order(dm):
     assert full["qpos"].shape == (4096, 7) and np.array_equal(full["qpos"][-50:], after["qpos"])
     assert p.status() & 1 == 0
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [64, 40000])
+def test_read_step_after_every_way_of_advancing(dm, K):
+    """`mppi_read_step` hands back the newest log row and the shifted act_sequence.  A single planner's last step may
+    have written them to host memory by itself (a lone advance, a single captured step) or not (the steps of a captured
+    run; anything that touched act_sequence afterwards): whichever way the step was made, the answer is what the device
+    holds.  (K = 40000: the advance launch carries no noise blocks.)"""
+    from trajopt_amd.device import DevicePlanner
+    H = 6
+    p = DevicePlanner(dm, K, H, kappa=25.0, sigma=np.ones(7), betas=(0.25, 0.8, 0.0), default_act="mean")
+    p.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, 0.0, 0.1]), 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    steps = 0
+
+    def check(what):
+        rows, seq = p.read_step()
+        log = p.read_log(max_rows=1)
+        assert log["total"] == steps, what
+        assert np.array_equal(seq, p.act_sequence()), what
+        assert np.array_equal(rows[:7], log["qpos"][0]) and np.array_equal(rows[7:14], log["qvel"][0]), what
+        assert rows[20] == log["reward"][0] and np.array_equal(rows[21:], log["action"][0]), what
+        return rows, seq
+
+    for n in (1, 1, 8, 9, 3, 16):                     # single captured steps, whole runs, runs with a remainder
+        p.plan(7, 1, n)
+        steps += n
+        check("plan %d" % n)
+    p.generate_noise(3)
+    p.iterate(1)
+    p.advance()                                       # a lone advance behind an iteration
+    steps += 1
+    rows, _ = check("advance")
+    p.advance_noise(9)
+    steps += 1
+    check("advance_noise")
+    p.iterate(1)                                      # the update rewrites act_sequence after the mirrored step
+    check("iterate after the step")
+    new = np.arange(H * 7, dtype=float).reshape(H, 7) / 50.0
+    p.plan(7, 1, 1)
+    steps += 1
+    p.set_base_actions(new)                           # ... and so does the caller
+    _, seq = check("set_base_actions after the step")
+    assert np.array_equal(seq, new)
+    p.plan(7, 1, 1)
+    steps += 1
+    a = check("plan 1")
+    b = check("read twice")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert p.status() == 0
+    p.close()

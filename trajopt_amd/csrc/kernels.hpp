@@ -337,13 +337,14 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
                                               const double* __restrict__ ref, int reward_type, int H, int tail_mode,
                                               const double* __restrict__ mean, double* __restrict__ log, int log_cap,
                                               int* __restrict__ log_count, double* __restrict__ last_row,
-                                              int* __restrict__ status) {
+                                              int* __restrict__ status, double* __restrict__ mirror) {
     constexpr int NV = MD::NV, NQ = MD::NQ;
     constexpr int ROW = NQ + 2 * NV + 7;
     constexpr int PER = 16;                       // H * NV <= 256 * PER
     const int tid = threadIdx.x;
     double keep[PER];
     const int HM = H * NV;
+    int steps_logged = 0;                                        // (thread 0 only)
     st += pl; base += (size_t)pl * HM;                           // one block per planner
     log += (size_t)pl * log_cap * ROW; log_count += pl;
 #pragma unroll
@@ -394,6 +395,7 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
         static_for<7>([&](auto Ic) { last[NQ + NV + Ic] = row[NQ + NV + Ic]; });
         st->timestep = t0 + 1;
         *log_count = n + 1;
+        steps_logged = n + 1;
     }
     __syncthreads();
 #pragma unroll
@@ -401,14 +403,30 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
         const int i = tid + 256 * u;
         if (i < HM) base[i] = keep[u];
     }
+    // The same outcome -- newest log row, shifted act_sequence, then the number of steps logged -- written to
+    // page-locked host memory for a host that reads every step back (mppi_read_step): it sees the count change as
+    // soon as the data are there, without a copy or a wait on the stream.  [ROW | H * NV | count]
+    if (mirror) {
+        if (tid < ROW) mirror[tid] = last_row[(size_t)pl * ROW + tid];       // (written by thread 0 before the barrier)
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = tid + 256 * u;
+            if (i < HM) mirror[ROW + i] = keep[u];
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(mirror + ROW + HM), (unsigned long long)steps_logged,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 template <class MD>
 __global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
                                                       const double* __restrict__ ref, int reward_type, int H, int tail_mode,
                                                       const double* __restrict__ mean, double* __restrict__ log, int log_cap,
                                                       int* __restrict__ log_count, double* __restrict__ last_row,
-                                                      int* __restrict__ status) {
-    advance_block<MD>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status);
+                                                      int* __restrict__ status, double* __restrict__ mirror) {
+    advance_block<MD>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status, mirror);
 }
 // advance_kernel and, in the blocks behind the first of every planner, the Philox noise of the NEXT planning step
 // (stream key seed + next_step[planner], published by the rollouts of the current step): the noise does not depend
@@ -420,8 +438,9 @@ __global__ void __launch_bounds__(256) advance_noise_kernel(DevState* __restrict
                                                             int* __restrict__ log_count, double* __restrict__ last_row,
                                                             int* __restrict__ status, int K, int k_offset, uint32_t seed_lo,
                                                             uint32_t seed_hi, const int* __restrict__ next_step, FilterCoefs fc,
-                                                            T* __restrict__ eps, uint32_t* __restrict__ key_out) {
-    if (blockIdx.x == 0) advance_block<MD>(blockIdx.y, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status);
+                                                            T* __restrict__ eps, uint32_t* __restrict__ key_out,
+                                                            double* __restrict__ mirror) {
+    if (blockIdx.x == 0) advance_block<MD>(blockIdx.y, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status, mirror);
     else noise_philox_block<T, MD::NV>(blockIdx.x - 1, blockIdx.y, K, H, k_offset, seed_lo, seed_hi, next_step[blockIdx.y], 1, fc, eps, key_out);
 }
 
@@ -825,13 +844,14 @@ struct ModelOps {
     hipError_t (*noise_philox)(int dtype, int K, int H, int P, int k_offset, uint64_t seed, const DevState* st, int seed_from_state,
                                const FilterCoefs&, void* eps, uint32_t* key_out, hipStream_t);
     hipError_t (*advance)(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
-                          const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status, hipStream_t);
+                          const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status,
+                          double* mirror, hipStream_t);
     hipError_t (*env_step)(const double* in, int reward_type, int has_ref, int forward_only, double* out, hipStream_t);
     hipError_t (*critic)(int dtype, const void* fobs, int K, int P, int dim, const float* w, double g_last, void* R, hipStream_t);
     hipError_t (*advance_noise)(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                 const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status,
                                 int K, int k_offset, uint64_t seed, const int* next_step, const FilterCoefs& fc, void* eps,
-                                uint32_t* key_out, hipStream_t);
+                                uint32_t* key_out, double* mirror, hipStream_t);
     // the update of batched planners from noise drawn again (update_regen_kernel); false: no kernel for this shape
     bool (*update_regen_fits)(int K, int H, int P);
     hipError_t (*update_regen)(int dtype, const void* R, int K, int H, int P, double kappa, int k_offset, int write_base, double* base,
@@ -949,24 +969,25 @@ static hipError_t launch_update_regen(int dtype, const void* R, int K, int H, in
 template <class MD>
 static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                  const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status,
-                                 hipStream_t s) {
+                                 double* mirror, hipStream_t s) {
     hipLaunchKernelGGL((advance_kernel<MD>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap,
-                       log_count, last_row, status);
+                       log_count, last_row, status, P == 1 ? mirror : nullptr);
     return hipGetLastError();
 }
 template <class MD>
 static hipError_t launch_advance_noise(int dtype, DevState* st, double* base, const double* ref, int reward_type, int H, int P,
                                        int tail_mode, const double* mean, double* log, int log_cap, int* log_count,
                                        double* last_row, int* status, int K, int k_offset, uint64_t seed, const int* next_step,
-                                       const FilterCoefs& fc, void* eps, uint32_t* key_out, hipStream_t s) {
+                                       const FilterCoefs& fc, void* eps, uint32_t* key_out, double* mirror, hipStream_t s) {
     const dim3 grid(1 + (K * MD::NV + 255) / 256, P), block(256);
+    if (P != 1) mirror = nullptr;          // the host mirror serves single planners
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((advance_noise_kernel<float, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (float*)eps, key_out);
+                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (float*)eps, key_out, mirror);
     else
         hipLaunchKernelGGL((advance_noise_kernel<double, MD>), grid, block, 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
-                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (double*)eps, key_out);
+                           log_cap, log_count, last_row, status, K, k_offset, lo, hi, next_step, fc, (double*)eps, key_out, mirror);
     return hipGetLastError();
 }
 template <class MD>

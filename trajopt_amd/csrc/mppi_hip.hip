@@ -312,6 +312,13 @@ struct mppi_planner {
     int* d_log_count;
     double* d_last_row;    // [P][3M+7] the newest log row of every planner (mppi_read_step)
     double* h_step;        // page-locked [P][3M+7 + H*M]: where mppi_read_step lands its two copies
+    // Host mirror of a single planner's newest step (advance_block writes it): [3M+7 | H*M | count of steps logged] in
+    // page-locked host memory the device writes to directly; d_mirror is the same memory as the device sees it.
+    double* h_mirror;
+    double* d_mirror;
+    uint64_t advances;     // real-env steps enqueued so far (= the count the device will have logged after them) ...
+    uint64_t mirror_at;    // ... and the value of that count after the last step that was asked to write the mirror
+    hipStream_t adv_stream;        // stream the last advance was enqueued on
     int* d_next_step;      // [P] index of the planning step after the one being rolled out
     uint32_t* d_noise_key; // [P][2] stream key the Philox noise in d_eps was drawn with (written by the noise kernels)
     bool eps_philox;       // d_eps holds Philox noise (the update may draw it again instead of reading it)
@@ -422,6 +429,12 @@ static int planner_allocate(mppi_planner* p) {
     HIP_OK(hipMalloc(&p->d_last_row, P * (p->nq + 2 * p->nv + 7) * 8));
     HIP_OK(hipMemset(p->d_last_row, 0, P * (p->nq + 2 * p->nv + 7) * 8));
     HIP_OK(hipHostMalloc(&p->h_step, (P * (p->nq + 2 * p->nv + 7) + HM) * 8, hipHostMallocDefault));
+    if (P == 1) {
+        const size_t n = (size_t)(p->nq + 2 * p->nv + 7) + p->HM + 1;
+        HIP_OK(hipHostMalloc(&p->h_mirror, n * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(p->h_mirror, 0, n * 8);
+        HIP_OK(hipHostGetDevicePointer((void**)&p->d_mirror, p->h_mirror, 0));
+    }
     if (cfg->dump) {
         HIP_OK(hipMalloc(&p->d_obs, K * cfg->H * OD * p->esz));
         HIP_OK(hipMalloc(&p->d_rew, K * cfg->H * p->esz));
@@ -437,6 +450,17 @@ static int planner_allocate(mppi_planner* p) {
 }
 
 extern "C" {
+
+// Bookkeeping of the host mirror (see mppi_planner::h_mirror): an enqueued real-env step that was asked to write it
+// makes it current; anything else that changes act_sequence on the device makes it stale.
+static double* mirror_for(mppi_planner* p, bool wanted) { return (wanted && p->P == 1) ? p->d_mirror : nullptr; }
+static void advanced(mppi_planner* p, int steps, bool last_wrote_mirror, hipStream_t s) {
+    p->advances += (uint64_t)steps;
+    p->mirror_at = (last_wrote_mirror && p->P == 1 && p->d_mirror) ? p->advances : 0;
+    p->adv_stream = s;
+    for (DevState& st : *p->h_state) st.timestep += steps;
+}
+static void act_sequence_changed(mppi_planner* p) { p->mirror_at = 0; }
 
 int mppi_version(void) { return MPPI_ABI_VERSION; }
 const char* mppi_last_error(void) { return g_err.c_str(); }
@@ -529,6 +553,7 @@ void mppi_planner_destroy(mppi_planner* p) {
     if (p->d_gathered) (void)hipFree(p->d_gathered);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
     if (p->h_step) (void)hipHostFree(p->h_step);
+    if (p->h_mirror) (void)hipHostFree(p->h_mirror);
     if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
     if (p->ev_raw_free) (void)hipEventDestroy(p->ev_raw_free);
     if (p->ev_upload_done) (void)hipEventDestroy(p->ev_upload_done);
@@ -575,6 +600,7 @@ int mppi_set_base_actions(mppi_planner* p, const double* act) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipMemcpyAsync(p->d_base, act, (size_t)p->HM * p->P * 8, hipMemcpyDefault, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
+    act_sequence_changed(p);
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -765,9 +791,10 @@ int mppi_advance(mppi_planner* p, void* stream) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     const int rc = reference_covers(p, 1, env_reward(p));
     if (rc) return rc;
+    hipStream_t s = pick(p, stream);
     HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
-                                  p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, pick(p, stream)));
-    for (DevState& st : *p->h_state) st.timestep++;
+                                  p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, mirror_for(p, true), s));
+    advanced(p, 1, true, s);
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -779,11 +806,12 @@ int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream) try {
     HIP_OK(hipSetDevice(p->cfg.device));
     const int rc = reference_covers(p, 1, env_reward(p));
     if (rc) return rc;
+    hipStream_t s = pick(p, stream);
     HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P,
                                         p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
                                         p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps,
-                                        p->d_noise_key, pick(p, stream)));
-    for (DevState& st : *p->h_state) st.timestep++;
+                                        p->d_noise_key, mirror_for(p, true), s));
+    advanced(p, 1, true, s);
     set_eps_source(p, true);
     p->explicit_act = 0;
     p->noise_ahead = true;
@@ -962,6 +990,7 @@ int mppi_partials_ptr(mppi_planner* p, void** ptr, size_t* bytes) try {
 int mppi_merge(mppi_planner* p, const void* gathered, int32_t nranks, void* stream) try {
     if (!p || !gathered || nranks < 1) return fail(-1, "bad argument");
     HIP_OK(hipSetDevice(p->cfg.device));
+    act_sequence_changed(p);
     return launch_merge(p, (const double*)gathered, nranks, pick(p, stream));
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
@@ -993,6 +1022,7 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) try {
     if (niter > 0) {
         const int rc = reference_covers(p, p->cfg.H, p->cfg.reward_type);
         if (rc) return rc;
+        act_sequence_changed(p);
     }
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
@@ -1019,7 +1049,7 @@ int mppi_iterate(mppi_planner* p, int32_t niter, void* stream) try {
 static bool plan_draws_ahead(const mppi_planner* p) { return (long)p->cfg.K * p->P <= 32768; }
 
 // niter x (rollouts, update), then the real-env step; the noise of this step must be in place
-static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStream_t s) {
+static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, bool mirror, hipStream_t s) {
     for (int i = 0; i < niter; i++) {
         int rc = launch_rollout_only(p, s);
         if (!rc) rc = launch_update(p, s);
@@ -1029,10 +1059,11 @@ static int enqueue_plan_body(mppi_planner* p, uint64_t seed, int niter, hipStrea
         HIP_OK(p->model->ops->advance_noise(p->cfg.dtype, p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P,
                                             p->cfg.default_act, p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row,
                                             p->d_status, p->cfg.K, p->cfg.k_offset, seed, p->d_next_step, p->fc, p->d_eps,
-                                            p->d_noise_key, s));
+                                            p->d_noise_key, mirror_for(p, mirror), s));
     else
         HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P, p->cfg.default_act,
-                                      p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, s));
+                                      p->d_mean, p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status,
+                                      mirror_for(p, mirror), s));
     return 0;
 }
 static int enqueue_plan_noise(mppi_planner* p, uint64_t seed, hipStream_t s) {
@@ -1049,7 +1080,9 @@ static int capture_steps(mppi_planner* p, uint64_t seed, int niter, int steps, b
     int rc = 0;
     for (int i = 0; i < steps && !rc; i++) {
         rc = ahead ? 0 : enqueue_plan_noise(p, seed, p->stream);
-        if (!rc) rc = enqueue_plan_body(p, seed, niter, p->stream);
+        // a captured single step writes the host mirror (its caller reads every step back); the steps of a captured
+        // run do not: nobody reads between them, and a write to host memory is not free
+        if (!rc) rc = enqueue_plan_body(p, seed, niter, steps == 1, p->stream);
     }
     hipError_t e = hipStreamEndCapture(p->stream, &g);
     if (rc) {
@@ -1079,13 +1112,15 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
     const bool ahead = plan_draws_ahead(p);
     // with noise drawn ahead only the first step of a run needs a launch of its own
     const bool have_noise = ahead && p->noise_ahead && p->noise_ahead_seed == seed;
+    bool last_wrote_mirror = false;
     static const bool use_graph = [] { const char* e = getenv("MPPI_GRAPH"); return !(e && e[0] == '0'); }();
     if (!use_graph || p->profiling) {
         for (int i = 0; i < nsteps; i++) {
             int rc = (ahead && (i > 0 || have_noise)) ? 0 : enqueue_plan_noise(p, seed, s);
-            if (!rc) rc = enqueue_plan_body(p, seed, niter, s);
+            if (!rc) rc = enqueue_plan_body(p, seed, niter, i == nsteps - 1, s);
             if (rc) return rc;
         }
+        last_wrote_mirror = true;
     } else {
         if (!p->step_graph || p->step_graph_gen != p->cfg_gen || p->step_graph_niter != niter || p->step_graph_seed != seed) {
             if (p->step_graph) { HIP_OK(hipGraphExecDestroy(p->step_graph)); p->step_graph = nullptr; }
@@ -1107,24 +1142,51 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
         if (ahead && !have_noise) { const int rc = enqueue_plan_noise(p, seed, s); if (rc) return rc; }
         int left = nsteps;
         for (; left >= PLAN_RUN; left -= PLAN_RUN) HIP_OK(hipGraphLaunch(p->step_graph_run, s));
+        last_wrote_mirror = left > 0;
         for (; left > 0; left--) HIP_OK(hipGraphLaunch(p->step_graph, s));
     }
     p->noise_ahead = ahead;
     p->noise_ahead_seed = seed;
-    for (DevState& st : *p->h_state) st.timestep += nsteps;
+    advanced(p, nsteps, last_wrote_mirror, s);
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());
+}
+
+// Waits until the device has written the outcome of real-env step number `expect` to the host mirror.  false: the
+// stream drained (or failed) without that happening -- the caller then copies the slow way, which also surfaces errors.
+static bool mirror_arrived(mppi_planner* p, uint64_t expect) {
+    const size_t at = (size_t)(p->nq + 2 * p->nv + 7) + p->HM;
+    const uint64_t* count = reinterpret_cast<const uint64_t*>(p->h_mirror + at);
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(count, __ATOMIC_ACQUIRE) == expect) return true;
+        if ((spins & 1023) == 0) {
+            // a kernel that never runs must not hang the host: look at the stream now and then
+            const hipError_t q = hipStreamQuery(p->adv_stream ? p->adv_stream : p->stream);
+            if (q != hipErrorNotReady) return __atomic_load_n(count, __ATOMIC_ACQUIRE) == expect;
+            (void)hipGetLastError();              // "not ready" is an answer, not an error to be found by a later check
+        }
+        if (spins < 4096) __builtin_ia32_pause();
+        else std::this_thread::yield();           // a long step (many samples): leave the processor to others
+    }
 }
 
 int mppi_read_step(mppi_planner* p, double* rows, double* act_seq) try {
     if (!p || (!rows && !act_seq)) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     const size_t nrow = (size_t)p->P * (p->nq + 2 * p->nv + 7), nseq = (size_t)p->HM * p->P;
-    // two small copies into page-locked memory behind whatever the planner's stream still holds, one wait
-    if (rows) HIP_OK(hipMemcpyAsync(p->h_step, p->d_last_row, nrow * 8, hipMemcpyDeviceToHost, p->stream));
-    if (act_seq) HIP_OK(hipMemcpyAsync(p->h_step + nrow, p->d_base, nseq * 8, hipMemcpyDeviceToHost, p->stream));
-    HIP_OK(hipStreamSynchronize(p->stream));
+    // A single planner whose newest step wrote the host mirror and whose act_sequence nothing has touched since: the
+    // data arrive in host memory by themselves, the count last (no copy, no wait on the stream).
+    if (p->h_mirror && p->mirror_at != 0 && p->mirror_at == p->advances && mirror_arrived(p, p->mirror_at)) {
+        if (rows) std::memcpy(rows, p->h_mirror, nrow * 8);
+        if (act_seq) std::memcpy(act_seq, p->h_mirror + nrow, nseq * 8);
+        return 0;
+    }
+    // two small copies into page-locked memory behind whatever the stream of the last step still holds, one wait
+    hipStream_t s = p->adv_stream ? p->adv_stream : p->stream;
+    if (rows) HIP_OK(hipMemcpyAsync(p->h_step, p->d_last_row, nrow * 8, hipMemcpyDeviceToHost, s));
+    if (act_seq) HIP_OK(hipMemcpyAsync(p->h_step + nrow, p->d_base, nseq * 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
     if (rows) std::memcpy(rows, p->h_step, nrow * 8);
     if (act_seq) std::memcpy(act_seq, p->h_step + nrow, nseq * 8);
     return 0;
@@ -1136,6 +1198,7 @@ int mppi_shift(mppi_planner* p, const double* override_seq, void* stream) try {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));
     hipStream_t s = pick(p, stream);
+    act_sequence_changed(p);
     if (override_seq) {
         HIP_OK(hipMemcpyAsync(p->d_base, override_seq, (size_t)p->HM * p->P * 8, hipMemcpyDefault, s));
         HIP_OK(hipStreamSynchronize(s));

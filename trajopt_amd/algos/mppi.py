@@ -107,15 +107,16 @@ class MPPI(Trajectory):
     # ---- device planner -----------------------------------------------------------------
     def _device_planner(self):
         sigma, b0, b1, b2 = self.filter_coefs
-        sig = tuple(np.broadcast_to(np.asarray(sigma, dtype=np.float64), (self.m,)))
-        key = (self.env.env_name, self.H, self.paths_per_cpu, self.num_cpu, sig, b0, b1, b2, self.dtype,
-               tuple(np.asarray(self.mean, float)), self.default_act)
+        # (compared as raw bytes: this runs at every planning step, and the arrays are seven numbers long)
+        key = (self.env.env_name, self.H, self.paths_per_cpu, self.num_cpu, np.asarray(sigma, dtype=np.float64).tobytes(),
+               b0, b1, b2, self.dtype, np.asarray(self.mean, dtype=np.float64).tobytes(), self.default_act)
         if self._planner is None or key != self._planner_key:
             if self._planner is not None:
                 self._planner.close()
             self._ahead = None
             self._dev_state = self._dev_seq = None
             model = DeviceModel.get(_KERNEL_ENVS[self.env.env_name])
+            sig = tuple(np.broadcast_to(np.asarray(sigma, dtype=np.float64), (self.m,)))
             self._planner = DevicePlanner(model, self.paths_per_cpu * self.num_cpu, self.H, kappa=self.kappa,
                                           gamma=self.gamma, sigma=sig, betas=(b0, b1, b2), mean=self.mean,
                                           default_act=self.default_act, dtype=self.dtype)
@@ -193,10 +194,19 @@ class MPPI(Trajectory):
         rt = self.env.reward_type
         return rt if rt in ('sparse', 'tracking', 'cooling') else 'dense'
 
+    @staticmethod
+    def _state_record(p, s):
+        """What the device holds after being given (or having produced) state s, in a form that compares fast."""
+        return (id(p), np.asarray(s['qp'], dtype=np.float64).tobytes(), np.asarray(s['qv'], dtype=np.float64).tobytes(),
+                np.asarray(s['target_pos'], dtype=np.float64).tobytes(), int(s['timestep']))
+
     def _device_holds(self, p, s):
-        d = self._dev_state
-        return (d is not None and d[0] == id(p) and d[4] == s['timestep'] and np.array_equal(d[1], s['qp'])
-                and np.array_equal(d[2], s['qv']) and np.array_equal(d[3], s['target_pos']))
+        return self._dev_state is not None and self._dev_state == self._state_record(p, s)
+
+    def _device_holds_sequence(self, p):
+        d = self._dev_seq
+        return (d is not None and d[0] == id(p) and np.shape(self.act_sequence) == (self.H, self.m)
+                and np.asarray(self.act_sequence, dtype=np.float64).tobytes() == d[1])
 
     def _plan_on_device(self, seed, niter, critic_dim=0, critic_weights=None, advance=False):
         """niter iterations on the device from sol_state[-1] and act_sequence.  advance: also `advance_time` there
@@ -216,7 +226,7 @@ class MPPI(Trajectory):
         if not self._device_holds(p, s):
             p.set_start_state(s['qp'], s['qv'], s['target_pos'], s['timestep'])
         p.set_reference(reference if tracked else None, self.env.alpha)
-        if self._dev_seq is None or self._dev_seq[0] != id(p) or not np.array_equal(self._dev_seq[1], self.act_sequence):
+        if not self._device_holds_sequence(p):
             p.set_base_actions(self.act_sequence)
         self._dev_state = self._dev_seq = None           # until the outcome of this step has been read back
         p.set_critic(critic_dim, critic_weights)         # a no-op while dim and weights stay what they were
@@ -255,9 +265,8 @@ class MPPI(Trajectory):
                 self._ahead = ((id(p), seed + 1, self.paths_per_cpu, self.num_cpu, H, self.m), draw(seed + 1))
         if not advance:
             self.act_sequence = p.act_sequence()
-            self._dev_seq = (id(p), self.act_sequence.copy())
-            self._dev_state = (id(p), np.array(s['qp'], dtype=float), np.array(s['qv'], dtype=float),
-                               np.array(s['target_pos'], dtype=float), s['timestep'])
+            self._dev_seq = (id(p), self.act_sequence.tobytes())
+            self._dev_state = self._state_record(p, s)
             return
         # `advance_time` (trajopt/algos/mppi.py:67-89) from the device's log row
         row, seq = p.read_step()
@@ -270,8 +279,8 @@ class MPPI(Trajectory):
         self.sol_obs.append(self.env._get_obs(goal_dist=True))
         self.sol_reward.append(float(r))
         self.act_sequence = seq
-        self._dev_seq = (id(p), seq.copy())
-        self._dev_state = (id(p), after['qp'], after['qv'], after['target_pos'], after['timestep'])
+        self._dev_seq = (id(p), seq.tobytes())
+        self._dev_state = self._state_record(p, after)
 
     def _attach_critic_rewards(self, paths, critic, dim):
         """Terminal-value inputs by `dim` (trajopt/algos/mppi.py:134-159, 191)."""

@@ -1,4 +1,9 @@
-"""The actor-critic use of the planner as the reference's script wires it (sandbox/examples/ac_reacher_7dof_mppi.py:
+"""The flows of the reference's example scripts on the GPU planner, step by step against the CPU oracle.
+
+The main example (sandbox/examples/reacher_7dof_mppi.py): tracking the stored dense agent's hand trajectory -- see
+test_main_example_script_tracks_the_stored_agent.
+
+The actor-critic use of the planner as the reference's script wires it (sandbox/examples/ac_reacher_7dof_mppi.py:
 146-229): the rollouts are scored with the 'cooling' reward against the hand positions of a stored dense solution
 (alpha cooled from epoch to epoch) and end in the critic's value (trajopt/algos/mppi.py:95-101, 134-159), the real
 environment reports the sparse reward, every epoch builds a new `MPPI`, the solution goes through
@@ -141,3 +146,59 @@ def test_example_actor_critic_script():
     assert [round(r[0], 6) for r in results] == [1.0, 0.9]
     for alpha, ret, dist, loss in results:
         assert -40.0 * 100.0 <= ret <= 40.0 * 100.0 and np.isfinite(dist) and dist < 0.6 and np.isfinite(loss)
+
+
+def _stored_dense_agent_states(transitions):
+    """qpos / qvel of the 117 states of the reference's stored `dense_agent.pickle` (its 116 transitions are part of
+    tests/golden/reference_transitions.npz)."""
+    d = transitions
+    m = d["file_id"] == [str(n) for n in d["file_names"]].index("dense_agent.pickle")
+    order = np.argsort(d["step"][m])
+    qp = np.concatenate((d["qp"][m][order], d["qp_next"][m][order][-1:]))
+    qv = np.concatenate((d["qv"][m][order], d["qv_next"][m][order][-1:]))
+    assert len(qp) == 117 and np.array_equal(qp[1:-1], d["qp_next"][m][order][:-1])
+    return qp, qv
+
+
+def test_main_example_script_tracks_the_stored_agent(oracle_sim, transitions):
+    """The reference's main example (sandbox/examples/reacher_7dof_mppi.py:19-50): the hand trajectory of the stored
+    dense agent, read through `env.data.site_xpos`, is the reference of a 'tracking' environment and planner (H = 16,
+    K = 40, five updates per step, seed 3, 100 steps).  fp64, every step against the oracle restarted from the agent's
+    own state; the step after the reference runs out raises IndexError like `self.reference[self.env_timestep]`."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    qp, qv = _stored_dense_agent_states(transitions)
+    goal = np.zeros(3)
+    probe = get_environment('reacher_7dof')
+    reference = []
+    for t in range(len(qp)):
+        probe.set_env_state(dict(qp=qp[t], qv=qv[t], target_pos=goal, timestep=t))
+        reference.append(np.array(probe.data.site_xpos[probe.hand_sid]))
+    reference = np.array(reference)
+    assert reference.shape == (117, 3) and np.linalg.norm(reference[-1]) < 0.05        # the stored agent reached the goal
+
+    e = get_environment('reacher_7dof', reward_type='tracking', reference=reference)
+    e.reset_model(seed=3, goal=(0, 0, 0), alpha=1.0)
+    ag = MPPI(e, H=H, paths_per_cpu=K, num_cpu=1, kappa=25.0, gamma=1.0, mean=np.zeros(7), filter_coefs=FILTER,
+              default_act='mean', seed=3, reward_type='tracking', reference=reference, dtype="f64")
+    assert ag._real_env_steps_on_the_device()
+    worst = worst_seq = 0.0
+    for t in range(100):
+        s0, seq = ag.sol_state[-1], ag.act_sequence.copy()
+        ag.train_step(niter=NITER, goal=(0, 0, 0))
+        eps = ref_mppi.filter_noise(ref_mppi.all_raw_normals(3 + t, K, 1, H, 7), FILTER)
+        for _ in range(NITER):
+            R = oracle_sim.rollout(s0["qp"], s0["qv"], goal, t, seq + eps, reward_type="tracking", reference=reference)
+            seq = ref_mppi.update(seq + eps, R, 25.0)
+        q, v, _, r, _ = oracle_sim.env_step(s0["qp"], s0["qv"], goal, seq[0], t, reward_type="tracking", reference=reference)
+        worst = max(worst, np.abs(ag.sol_state[-1]["qp"] - q).max(), np.abs(ag.sol_state[-1]["qv"] - v).max(),
+                    abs(ag.sol_reward[-1] - r))
+        worst_seq = max(worst_seq, np.abs(ag.act_sequence - ref_mppi.shift(seq, "mean", np.zeros(7))).max())
+    assert worst < 1e-8 and worst_seq < 1e-6, (worst, worst_seq)
+    # the planner follows the stored hand trajectory: mean distance to the tracked point of a few centimetres
+    hand = np.array([o[14:17] for o in ag.sol_obs[1:]])
+    assert np.linalg.norm(hand - reference[1:101], axis=1).mean() < 0.1
+    assert len(ag.sol_state) == 101 and ag.sol_state[-1]["timestep"] == 100
+    ag.train_step(niter=1, goal=(0, 0, 0))               # time step 100: rows up to 116 are read
+    with pytest.raises(IndexError):
+        ag.train_step(niter=1, goal=(0, 0, 0))           # time step 101 would read row 117

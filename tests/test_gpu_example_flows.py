@@ -202,3 +202,14 @@ def test_main_example_script_tracks_the_stored_agent(oracle_sim, transitions):
     ag.train_step(niter=1, goal=(0, 0, 0))               # time step 100: rows up to 116 are read
     with pytest.raises(IndexError):
         ag.train_step(niter=1, goal=(0, 0, 0))           # time step 101 would read row 117
+
+
+def test_example_tracking_script():
+    """examples/reacher_tracking.py end to end (short): a dense solution planned, then tracked."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "reacher_tracking.py")
+    spec = importlib.util.spec_from_file_location("reacher_tracking", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    total, mean_gap, final_gap = mod.main(["--steps", "50"])
+    assert np.isfinite(total) and mean_gap < 0.15 and final_gap < 0.15

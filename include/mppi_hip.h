@@ -56,7 +56,8 @@ enum {
 };
 
 enum {
-    MPPI_STATUS_NONFINITE = 1,  /* a rollout returned NaN or infinity                                             */
+    MPPI_STATUS_NONFINITE = 1,  /* a rollout returned NaN or infinity (the simulation diverged); such a sample    */
+                                /* has weight zero in the planner's updates                                      */
     MPPI_STATUS_SWEEP_CAP = 2,  /* an active-set solve of the constraint rows stopped at cfg.sweep_cap sweeps     */
     MPPI_STATUS_REF_END = 4     /* a tracking / cooling reward asked for a row past the end of the reference      */
                                 /* trajectory (IndexError in trajopt/envs/reacher_env.py:61,75); the last row was */

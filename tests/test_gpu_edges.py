@@ -325,3 +325,40 @@ def test_read_step_after_every_way_of_advancing(dm, K):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert p.status() == 0
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_diverged_rollouts_take_no_part_in_the_update(dm, oracle_sim, dtype):
+    """From a start pose with the contact sphere deep inside the table plane the soft contact throws the arm so hard
+    that the explicit integrator diverges for some samples -- in the fp64 oracle exactly as on the device (same
+    samples).  Their returns are NaN and MPPI_STATUS_NONFINITE is set; the update gives them weight zero instead of
+    turning the whole action sequence into NaN (the reference's simulator resets itself when an acceleration stops
+    being finite, after rewards that have long weighed such a sample out)."""
+    K, H = 1024, 32
+    q0 = np.array([-2.09561976, 1.43984361, -1.5, 0.01131303, -1.06462017, -0.98820045, -0.73393196])
+    rs = np.random.RandomState(3)
+    raw = rs.normal(0, 1.0, (K, H, 7))
+    base = rs.normal(0, 0.5, (H, 7))
+    p = _p(dm, K, H, dtype, kappa=25.0)
+    p.set_start_state(q0, np.zeros(7), np.array([0.1, 0.0, 0.2]), 0)
+    p.set_base_actions(base)
+    p.upload_noise(raw)
+    p.iterate(1)
+    R = p.returns()
+    bad = ~np.isfinite(R)
+    assert p.status() & 1 and 0 < bad.sum() < K // 4, bad.sum()
+    act = base + ref_mppi.filter_noise(raw.copy(), FILTER)
+    R_o = oracle_sim.rollout(q0, np.zeros(7), np.array([0.1, 0.0, 0.2]), 0, act, nthreads=8)
+    if dtype == "f64":
+        assert np.array_equal(bad, ~np.isfinite(R_o))                    # the oracle diverges on the same samples
+        # (samples on their way to divergence carry returns of 1e6 .. 1e9 that no two summation orders share)
+        tame = ~bad & (np.abs(R_o) < 1e4)
+        assert tame.sum() > K // 2 and np.abs(R[tame] - R_o[tame]).max() < 1e-6 * np.abs(R_o[tame]).max()
+    seq = p.act_sequence()
+    assert np.isfinite(seq).all()
+    # the reference update of the samples that survived (fp32 planners hold the perturbations in fp32)
+    want = ref_mppi.update(act[~bad], R[~bad].astype(np.float64), 25.0)
+    assert np.abs(seq - want).max() < (1e-9 if dtype == "f64" else 1e-6)
+    assert p.argmax() == int(np.flatnonzero(~bad)[np.argmax(R[~bad])])
+    p.close()

@@ -593,6 +593,16 @@ __device__ __forceinline__ void argmax_combine(double& v, int& i, double ov, int
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 __device__ __forceinline__ double shfl_xor_d(double x, int m) { return __shfl_xor(x, m, 64); }
+// A rollout that diverged (a start state deep inside the table plane can do that to an explicit integrator) returns
+// NaN or infinity and sets MPPI_STATUS_NONFINITE.  Such a sample takes no part in the update: it cannot be the maximum
+// and its weight is zero, where exp(kappa (NaN - Rmax)) would turn the whole action sequence into NaN.  (The
+// reference's simulator resets itself when an acceleration stops being finite, after rewards that have long weighed
+// the sample out.)
+template <class T> __device__ __forceinline__ double return_for_max(T r) { return nonfinite(r) ? -DBL_MAX : (double)r; }
+template <class T> __device__ __forceinline__ double sample_weight(double kappa, T r, double rmax) {
+    const double w = exp(kappa * ((double)r - rmax));
+    return nonfinite(r) ? 0.0 : w;
+}
 
 // Update in one launch (write_base = 1), or one shard's statistics (Rmax, arg-max, sum S, sum S eps) for the
 // exchange between ranks (write_base = 0: act_sequence is left to the merge).  A block owns ROWS consecutive (step, action dimension) rows of one planner:
@@ -644,10 +654,10 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     #pragma unroll
             for (int e = 0; e < HOLD; e++) {
                 const int k = tid + e * nthreads;
-                if (k < K) argmax_combine(bv, bi, (double)rv[e], k);
+                if (k < K) argmax_combine(bv, bi, return_for_max(rv[e]), k);
             }
         } else {
-            for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
+            for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, return_for_max(R[k]), k);
         }
     #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -669,7 +679,7 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
         for (int e = 0; e < HOLD; e++) {
             const int k = tid + e * nthreads;
             if (k < K) {
-                const double sk = exp(kappa * ((double)rv[e] - bv));
+                const double sk = sample_weight(kappa, rv[e], bv);
 #pragma unroll
                 for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] = fma(sk, (double)ev[j][e], acc[j]);
                 acc[ROWS] += sk;
@@ -681,23 +691,25 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
         int k = tid;
         for (; k + (U - 1) * nthreads < K; k += U * nthreads) {
             double sk[U];
+            T ru[U];
             T e[ROWS][U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                sk[u] = weights ? weights[k + u * nthreads] : (double)R[k + u * nthreads];
+                if (weights) sk[u] = weights[k + u * nthreads];
+                else ru[u] = R[k + u * nthreads];
 #pragma unroll
                 for (int j = 0; j < ROWS; j++) e[j][u] = j < nr ? eps[(size_t)j * K + k + u * nthreads] : T(0);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (!weights) sk[u] = exp(kappa * (sk[u] - bv));
+                if (!weights) sk[u] = sample_weight(kappa, ru[u], bv);
 #pragma unroll
                 for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] = fma(sk[u], (double)e[j][u], acc[j]);
                 acc[ROWS] += sk[u];
             }
         }
         for (; k < K; k += nthreads) {
-            const double sk = weights ? weights[k] : exp(kappa * ((double)R[k] - bv));
+            const double sk = weights ? weights[k] : sample_weight(kappa, R[k], bv);
 #pragma unroll
             for (int j = 0; j < ROWS; j++) if (j < nr) acc[j] = fma(sk, (double)eps[(size_t)j * K + k], acc[j]);
             acc[ROWS] += sk;
@@ -723,8 +735,9 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
         part[3 + row0 + tid] = n;
     }
     if (blockIdx.x == 0 && tid == 0) {
-        part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
-        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + bi); }
+        const int best = bi == INT_MAX ? 0 : bi;          // (no sample with a finite return: none is the best)
+        part[0] = bv; part[1] = (double)(k_offset + best); part[2] = d;
+        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + best); }
     }
 }
 
@@ -750,7 +763,7 @@ __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__
     // Rmax and the first arg-max, as every block of update_rows_kernel finds them
     double bv = -DBL_MAX;
     int bi = INT_MAX;
-    for (int k = tid; k < K; k += 256) argmax_combine(bv, bi, (double)R[k], k);
+    for (int k = tid; k < K; k += 256) argmax_combine(bv, bi, return_for_max(R[k]), k);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const double ov = shfl_xor_d(bv, m);
@@ -766,7 +779,7 @@ __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__
 #pragma unroll
     for (int t = 0; t <= HT; t++) acc[t] = 0.0;
     for (int k = tid; k < K; k += 256) {
-        const double sk = exp(kappa * ((double)R[k] - bv));
+        const double sk = sample_weight(kappa, R[k], bv);
         // (fully unrolled: t is a constant in every call, the running sums stay in registers)
         philox_sequence<HT>((uint32_t)(k_offset + k), j, pl, key_lo, key_hi, H, fc,
                             [&](int t, double e) { acc[t] = fma(sk, (double)(T)e, acc[t]); });
@@ -792,8 +805,9 @@ __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__
         part[3 + t * NV + j] = n;
     }
     if (j == 0 && tid == 0) {
-        part[0] = bv; part[1] = (double)(k_offset + bi); part[2] = d;
-        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + bi); }
+        const int best = bi == INT_MAX ? 0 : bi;          // (no sample with a finite return: none is the best)
+        part[0] = bv; part[1] = (double)(k_offset + best); part[2] = d;
+        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + best); }
     }
 }
 
@@ -808,7 +822,7 @@ __global__ void __launch_bounds__(1024) update_weights_kernel(const T* __restric
     R += (size_t)blockIdx.y * K; out += (size_t)blockIdx.y * (K + 2);
     double bv = -DBL_MAX;
     int bi = INT_MAX;
-    for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, (double)R[k], k);
+    for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, return_for_max(R[k]), k);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const double ov = shfl_xor_d(bv, m);
@@ -820,7 +834,7 @@ __global__ void __launch_bounds__(1024) update_weights_kernel(const T* __restric
     bv = s_v[0]; bi = s_i[0];
     for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w], s_i[w]);
     const int per = (K + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < K ? lo + per : K;
-    for (int k = lo + tid; k < hi; k += nthreads) out[k] = exp(kappa * ((double)R[k] - bv));
+    for (int k = lo + tid; k < hi; k += nthreads) out[k] = sample_weight(kappa, R[k], bv);
     if (blockIdx.x == 0 && tid == 0) { out[K] = bv; out[K + 1] = (double)bi; }
 }
 

@@ -795,6 +795,7 @@ int mppi_advance(mppi_planner* p, void* stream) try {
     HIP_OK(p->model->ops->advance(p->d_state, p->d_base, p->d_ref, env_reward(p), p->cfg.H, p->P, p->cfg.default_act, p->d_mean,
                                   p->d_log, MPPI_LOG_CAP, p->d_log_count, p->d_last_row, p->d_status, mirror_for(p, true), s));
     advanced(p, 1, true, s);
+    p->noise_ahead = false;          // whatever noise the device holds was drawn for the step that has just ended
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());

@@ -67,8 +67,12 @@ def test_random_walk_over_the_entry_points(dtype, walk):
         assert np.array_equal(a.act_sequence(), b.act_sequence()), where
         assert a.status() == b.status() == 0, where
 
+    reference = np.cumsum(0.002 * rs.randn(2000, 3), axis=0) + np.array([0.6, -0.3, 0.2])
+    crit = [(0.3 * rs.randn(128, 14)).astype(np.float32), (0.1 * rs.randn(128)).astype(np.float32),
+            (0.1 * rs.randn(128, 128)).astype(np.float32), (0.1 * rs.randn(128)).astype(np.float32),
+            (3.0 * rs.randn(1, 128)).astype(np.float32), np.array([0.5], np.float32)]
     for _ in range(30):
-        op = rs.randint(10)
+        op = rs.randint(15)
         if op <= 2:                                   # mppi_plan: single steps, runs, runs with a remainder
             n = int(rs.choice([1, 1, 2, 3, 8, 9, 17]))
             a.plan(seed, niter, n)
@@ -113,6 +117,33 @@ def test_random_walk_over_the_entry_points(dtype, walk):
             q, v, t = 0.3 * rs.randn(7), rs.randn(7), int(rs.randint(0, 50))
             a.set_start_state(q, v, tgt, t); b.set_start_state(q, v, tgt, t)
             trace.append("start state, t = %d" % t)
+        elif op == 10:                                # rewards that read a reference trajectory; the real step's own reward
+            rt = str(rs.choice(["tracking", "cooling", "dense"]))
+            alpha = float(rs.choice([1.0, 0.6]))
+            env_rt = rs.choice(["sparse", "dense", None])
+            for p in (a, b):
+                p.set_reference(reference if rt != "dense" else None, alpha)
+                p.set_params(25.0, 1.0, rt)
+                p.set_env_reward(None if env_rt is None else str(env_rt))
+            trace.append("reward %s alpha %g env %s" % (rt, alpha, env_rt))
+        elif op == 11:                                # terminal-value critic on / off
+            on = rs.rand() < 0.6
+            for p in (a, b):
+                p.set_critic(14 if on else 0, crit if on else None)
+            trace.append("critic %s" % on)
+        elif op == 12:                                # rollouts alone: returns change, the log and act_sequence do not
+            a.generate_noise_step(seed); a.rollout()
+            same("rollout only")
+        elif op == 13:                                # the update as shard statistics + merge (one shard)
+            a.generate_noise_step(seed)
+            for _ in range(niter):
+                a.local_partials()
+                ptr, nbytes = a.partials_ptr()
+                a.merge(ptr, 1)
+            a.advance()
+            plain.step()
+            steps += 1
+            same("partials, merge, advance")
         else:                                         # ... or the action sequence
             seq = 0.2 * rs.randn(H, 7)
             a.set_base_actions(seq); b.set_base_actions(seq)
@@ -121,3 +152,93 @@ def test_random_walk_over_the_entry_points(dtype, walk):
             trace.append("act_sequence")
     assert steps > 0 or True
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("noise", ["philox", "host"])
+@pytest.mark.parametrize("walk", range(max(WALKS // 2, 2)))
+def test_random_walk_over_the_mppi_class(noise, walk):
+    """The same idea one level up: an `MPPI` agent whose `train_step` stays on the device (state and act_sequence are
+    re-sent only when the caller changed them, the real environment's step is made by the planner) against a twin that
+    sends everything at every step and steps its environment object itself, while the caller edits `act_sequence`,
+    `sol_state[-1]`, parameters and the critic between steps, or pickles the agent and goes on with the copy.  fp64, bit
+    for bit."""
+    import pickle
+    import torch
+    from trajopt.algos.mppi import MPPI, _critic_weights
+    from trajopt.envs.utils import get_environment
+    from trajopt.models.critic_nets import Critic
+    rs = np.random.RandomState(77 * walk + (noise == "host"))
+    H, K = int(rs.choice([6, 12])), int(rs.choice([40, 96]))
+    seed = int(rs.randint(1, 10 ** 5))
+    env_rt, rt = [("dense", "dense"), ("sparse", "cooling"), ("tracking", "tracking")][rs.randint(3)]
+    reference = np.cumsum(0.002 * rs.randn(400, 3), axis=0) + np.array([0.6, -0.3, 0.2])
+    goal = rs.uniform(-0.1, 0.1, 3)
+    torch.manual_seed(walk)
+    critic = Critic(input_dim=14)
+    with torch.no_grad():
+        critic.linear3.weight.mul_(20.0)
+
+    def agent():
+        e = get_environment('reacher_7dof', reward_type=env_rt, reference=reference if env_rt == "tracking" else None)
+        e.reset_model(seed=5, goal=goal, alpha=0.8)
+        return MPPI(e, H=H, paths_per_cpu=K, kappa=25.0, gamma=1.0, mean=np.zeros(7), filter_coefs=FILTER,
+                    default_act=str(rs.choice(["mean", "repeat"])), seed=seed, noise=noise, dtype="f64", reward_type=rt,
+                    reference=reference if rt != "dense" else None)
+    state = rs.get_state()
+    a = agent()
+    rs.set_state(state)
+    b = agent()
+    niter, use_critic, trace = 1, False, []
+    for _ in range(25):
+        op = rs.randint(9)
+        if op <= 3:
+            c = critic if use_critic else None
+            a.train_step(critic=c, niter=niter, goal=goal)
+            # the twin: everything sent again, iterations on the device, advance_time through the environment object
+            b._dev_state = b._dev_seq = None
+            b._plan_on_device(b.seed + len(b.sol_state) - 1, niter, 14 if use_critic else 0, _critic_weights(c, 14) if use_critic else None)
+            b.advance_time()
+            trace.append("step")
+            where = "%s %s/%s H=%d K=%d: %s" % (noise, env_rt, rt, H, K, " | ".join(trace))
+            for k in ("qp", "qv", "target_pos"):
+                assert np.array_equal(a.sol_state[-1][k], b.sol_state[-1][k]), (where, k)
+            assert a.sol_state[-1]["timestep"] == b.sol_state[-1]["timestep"] and a.sol_reward[-1] == b.sol_reward[-1], where
+            assert np.array_equal(a.act_sequence, b.act_sequence), (
+                where, np.abs(a.act_sequence - b.act_sequence).max(), np.argwhere(a.act_sequence != b.act_sequence).tolist(),
+                "returns equal: %s" % np.array_equal(a._planner.returns(), b._planner.returns()),
+                "noise equal: %s" % np.array_equal(a._planner.actions(), b._planner.actions()))
+            assert np.array_equal(a.sol_obs[-1], b.sol_obs[-1]), (where, a.sol_obs[-1] - b.sol_obs[-1], a.env.alpha, b.env.alpha)
+            assert np.array_equal(a.sol_act[-1], b.sol_act[-1]) and len(a.sol_state) == len(b.sol_state), where
+            sa, sb = a.env.get_env_state(), b.env.get_env_state()
+            assert np.array_equal(sa["qp"], sb["qp"]) and sa["timestep"] == sb["timestep"], where
+        elif op == 4:
+            d = 0.3 * rs.randn(2, 7)
+            a.act_sequence[1:3] += d; b.act_sequence[1:3] += d
+            trace.append("act_sequence edited in place")
+        elif op == 5:
+            new = 0.2 * rs.randn(H, 7)
+            a.act_sequence = new.copy(); b.act_sequence = new.copy()
+            trace.append("act_sequence rebound")
+        elif op == 6:
+            d = 0.05 * rs.randn(7)
+            if rs.rand() < 0.5:
+                a.sol_state[-1]["qp"][:] = a.sol_state[-1]["qp"] + d; b.sol_state[-1]["qp"][:] = b.sol_state[-1]["qp"] + d
+                trace.append("state edited in place")
+            else:
+                for ag in (a, b):
+                    s = ag.sol_state[-1]
+                    ag.sol_state[-1] = dict(qp=s["qp"] + d, qv=s["qv"] * 0.5, target_pos=s["target_pos"].copy(), timestep=s["timestep"])
+                trace.append("state replaced")
+        elif op == 7:
+            niter = int(rs.choice([1, 2, 3]))
+            use_critic = bool(rs.rand() < 0.5)
+            a.kappa = b.kappa = float(rs.choice([5.0, 25.0]))
+            trace.append("niter %d critic %s kappa %g" % (niter, use_critic, a.kappa))
+        else:
+            a = pickle.loads(pickle.dumps(a))
+            # (the environment is rebuilt from its constructor arguments, as gym's EzPickle does for the reference's:
+            # what `reset_model` had set -- alpha -- is the caller's to set again)
+            assert a.env.alpha == 1.0
+            a.env.alpha = b.env.alpha
+            trace.append("pickled")
+    assert len(a.sol_state) == len(b.sol_state)

@@ -18,10 +18,10 @@ FILTER = [np.ones(7), 0.25, 0.8, 0.0]
 WALKS = int(os.environ.get("MPPI_FUZZ_WALKS", "4"))
 
 
-def _planner(dm, K, H, dtype, default_act):
+def _planner(dm, K, H, dtype, default_act, P=1):
     from trajopt_amd.device import DevicePlanner
     return DevicePlanner(dm, K, H, kappa=25.0, gamma=1.0, sigma=FILTER[0], betas=FILTER[1:], mean=np.zeros(7),
-                         default_act=default_act, dtype=dtype)
+                         default_act=default_act, dtype=dtype, planners=P)
 
 
 class _Plain:
@@ -49,21 +49,25 @@ def test_random_walk_over_the_entry_points(dtype, walk):
     H = int(rs.choice([4, 9, 16]))
     default_act = str(rs.choice(["mean", "repeat"]))
     seed = int(rs.randint(1, 10 ** 6))
-    a, b = _planner(dm, K, H, dtype, default_act), _planner(dm, K, H, dtype, default_act)
+    # every third walk drives a handle of three planners (own states, own noise planes, own logs)
+    P = 3 if walk % 3 == 2 else 1
+    lead = (P,) if P > 1 else ()
+    a, b = _planner(dm, K, H, dtype, default_act, P), _planner(dm, K, H, dtype, default_act, P)
     plain = _Plain(b, seed)
-    q0, v0, tgt = 0.3 * rs.randn(7), rs.randn(7), rs.uniform(-0.2, 0.2, 3)
+    q0, v0, tgt = 0.3 * rs.randn(*lead, 7), rs.randn(*lead, 7), rs.uniform(-0.2, 0.2, lead + (3,))
     for p in (a, b):
         p.set_start_state(q0, v0, tgt, 0)
-        p.set_base_actions(np.zeros((H, 7)))
+        p.set_base_actions(np.zeros(lead + (H, 7)))
     niter, steps, trace = 1, 0, []
 
     def same(what):
         trace.append(what)
-        la, lb = a.read_log(max_rows=64), b.read_log(max_rows=64)
-        where = "K=%d H=%d %s: %s" % (K, H, default_act, " | ".join(trace))
-        assert la["total"] == lb["total"] == steps, (where, la["total"], lb["total"], steps)
-        for k in ("qpos", "qvel", "hand", "reward", "action"):
-            assert np.array_equal(la[k], lb[k]), (where, k, int(np.argmax((la[k] != lb[k]).any(axis=-1))), len(la[k]))
+        where = "P=%d K=%d H=%d %s: %s" % (P, K, H, default_act, " | ".join(trace))
+        for pl in range(P):
+            la, lb = a.read_log(max_rows=64, planner=pl), b.read_log(max_rows=64, planner=pl)
+            assert la["total"] == lb["total"] == steps, (where, la["total"], lb["total"], steps)
+            for k in ("qpos", "qvel", "hand", "reward", "action"):
+                assert np.array_equal(la[k], lb[k]), (where, pl, k, int(np.argmax((la[k] != lb[k]).any(axis=-1))), len(la[k]))
         assert np.array_equal(a.act_sequence(), b.act_sequence()), where
         assert a.status() == b.status() == 0, where
 
@@ -82,8 +86,8 @@ def test_random_walk_over_the_entry_points(dtype, walk):
             same("plan %d" % n)
             if rs.rand() < 0.5:                       # what a caller of single steps reads back
                 rows, seq = a.read_step()
-                lb = b.read_log(max_rows=1)
-                assert np.array_equal(rows[:7], lb["qpos"][0]) and np.array_equal(seq, b.act_sequence()), trace
+                lb = b.read_log(max_rows=1, planner=P - 1)
+                assert np.array_equal(rows[..., :7].reshape(P, 7)[P - 1], lb["qpos"][0]) and np.array_equal(seq, b.act_sequence()), trace
         elif op == 3:                                 # the plain sequence on both
             a.generate_noise_step(seed); a.iterate(niter); a.advance()
             plain.step()
@@ -100,7 +104,7 @@ def test_random_walk_over_the_entry_points(dtype, walk):
                 steps += 1
                 same("iterate on the noise drawn ahead, advance")
         elif op == 5:                                 # host noise for one step
-            raw = rs.randn(K, H, 7)
+            raw = rs.randn(*lead, K, H, 7)
             a.upload_noise(raw); a.iterate(niter); a.advance()
             plain.step(raw)
             steps += 1
@@ -114,7 +118,7 @@ def test_random_walk_over_the_entry_points(dtype, walk):
             niter = plain.niter = int(rs.choice([1, 2, 3]))
             trace.append("niter %d" % niter)
         elif op == 8:                                 # the caller moves the start state (time step included)
-            q, v, t = 0.3 * rs.randn(7), rs.randn(7), int(rs.randint(0, 50))
+            q, v, t = 0.3 * rs.randn(*lead, 7), rs.randn(*lead, 7), int(rs.randint(0, 50))
             a.set_start_state(q, v, tgt, t); b.set_start_state(q, v, tgt, t)
             trace.append("start state, t = %d" % t)
         elif op == 10:                                # rewards that read a reference trajectory; the real step's own reward
@@ -145,7 +149,7 @@ def test_random_walk_over_the_entry_points(dtype, walk):
             steps += 1
             same("partials, merge, advance")
         else:                                         # ... or the action sequence
-            seq = 0.2 * rs.randn(H, 7)
+            seq = 0.2 * rs.randn(*lead, H, 7)
             a.set_base_actions(seq); b.set_base_actions(seq)
             rows, got = a.read_step()                 # the mirror of the last step is stale now: the device's copy counts
             assert np.array_equal(got, seq), trace

@@ -75,8 +75,9 @@ def test_random_walk_over_the_entry_points(dtype, walk):
     crit = [(0.3 * rs.randn(128, 14)).astype(np.float32), (0.1 * rs.randn(128)).astype(np.float32),
             (0.1 * rs.randn(128, 128)).astype(np.float32), (0.1 * rs.randn(128)).astype(np.float32),
             (3.0 * rs.randn(1, 128)).astype(np.float32), np.array([0.5], np.float32)]
+    pending = None                                    # seed and worker count of host draws made ahead and not yet used
     for _ in range(30):
-        op = rs.randint(15)
+        op = rs.randint(17)
         if op <= 2:                                   # mppi_plan: single steps, runs, runs with a remainder
             n = int(rs.choice([1, 1, 2, 3, 8, 9, 17]))
             a.plan(seed, niter, n)
@@ -106,9 +107,26 @@ def test_random_walk_over_the_entry_points(dtype, walk):
         elif op == 5:                                 # host noise for one step
             raw = rs.randn(*lead, K, H, 7)
             a.upload_noise(raw); a.iterate(niter); a.advance()
+            pending = None                            # (the upload went through the staging area the draws waited in)
             plain.step(raw)
             steps += 1
             same("uploaded noise")
+        elif op >= 15:                                # numpy's worker streams drawn by the library (single planners)
+            if P > 1:
+                continue
+            from trajopt_amd.utils import worker_seeds
+            if pending is None:
+                pending = (int(rs.randint(0, 2 ** 31)), int(rs.choice([c for c in (1, 2, 4, 8) if K % c == 0])))
+                a.draw_noise(worker_seeds(pending[0], K // pending[1], pending[1]), int(rs.choice([1, 3, 16])))
+            sd, ncpu = pending
+            a.commit_noise(); a.iterate(niter); a.advance()
+            pending = None
+            if rs.rand() < 0.5:                       # the next step's draws made while the device still works on this one
+                pending = (int(rs.randint(0, 2 ** 31)), int(rs.choice([c for c in (1, 2, 4, 8) if K % c == 0])))
+                a.draw_noise(worker_seeds(pending[0], K // pending[1], pending[1]), int(rs.choice([1, 3, 16])))
+            plain.step(ref_mppi.all_raw_normals(sd, K // ncpu, ncpu, H, 7))       # numpy's own streams, uploaded
+            steps += 1
+            same("library-drawn host noise (%d workers)%s" % (ncpu, ", next drawn ahead" if pending else ""))
         elif op == 6:                                 # parameters (captured graphs must follow)
             kappa, gamma = float(rs.choice([1.0, 25.0, 60.0])), float(rs.choice([1.0, 0.95]))
             rt = str(rs.choice(["dense", "sparse"]))

@@ -264,3 +264,39 @@ def test_random_walk_over_the_mppi_class(noise, walk):
             a.env.alpha = b.env.alpha
             trace.append("pickled")
     assert len(a.sol_state) == len(b.sol_state)
+
+
+@pytest.mark.parametrize("case", range(max(2 * WALKS, 8)))
+def test_random_configurations_of_gather_paths_parallel(oracle_sim, case):
+    """`gather_paths_parallel` (trajopt/utils.py:148-163) over random horizons, worker layouts, filters (per-dimension
+    sigma, all three taps), reward types, start states and time steps: the paths the reference's list-of-dicts schema
+    carries, value by value against the oracle (fp64 rollouts, 1e-10)."""
+    from trajopt import utils
+    rs = np.random.RandomState(4242 + case)
+    H, ppc, ncpu = int(rs.randint(1, 40)), int(rs.randint(1, 70)), int(rs.choice([1, 2, 3, 5]))
+    filt = [rs.uniform(0.2, 1.5, 7), float(rs.uniform(0.1, 0.6)), float(rs.uniform(0.0, 0.9)), float(rs.choice([0.0, 0.15]))]
+    rt = str(rs.choice(["dense", "sparse", "tracking", "cooling"]))
+    t0 = int(rs.randint(0, 30))
+    reference = np.cumsum(0.004 * rs.randn(t0 + H + 5, 3), axis=0) + np.array([0.6, -0.3, 0.2]) if rt in ("tracking", "cooling") else None
+    alpha = float(rs.choice([1.0, 0.4]))
+    s = dict(qp=rs.uniform(-0.8, 0.8, 7) * np.array([1, 0.5, 1, 1, 1, 0.5, 1]), qv=rs.randn(7) * rs.choice([0.0, 2.0]),
+             target_pos=rs.uniform(-0.2, 0.2, 3), timestep=t0)
+    base = rs.randn(H, 7) * 0.3
+    seed = int(rs.randint(0, 2 ** 31))
+    utils.ROLLOUT_DTYPE = "f64"
+    try:
+        paths = utils.gather_paths_parallel('reacher_7dof', s, base, filt, seed, None, rt, reference, alpha, ppc, ncpu)
+    finally:
+        utils.ROLLOUT_DTYPE = "f32"
+    assert len(paths) == ppc * ncpu
+    act = base + ref_mppi.filter_noise(ref_mppi.all_raw_normals(seed, ppc, ncpu, H, 7), filt)
+    R_o, nobs_o, rew_o = oracle_sim.rollout(s["qp"], s["qv"], s["target_pos"], t0, act, reward_type=rt, reference=reference,
+                                            alpha=alpha, dump=True, nthreads=4)
+    what = (case, H, ppc, ncpu, rt)
+    for k in rs.choice(len(paths), size=min(len(paths), 12), replace=False):
+        p = paths[k]
+        assert np.array_equal(p["actions"], act[k]), what
+        assert np.abs(np.array(p["next_observations"]) - nobs_o[k]).max() < 1e-10, what
+        assert np.abs(p["rewards"] - rew_o[k]).max() < 1e-10 * (1 + np.abs(rew_o[k]).max()), what
+        assert p["observations"].shape == (H, 20) and (H == 1 or np.abs(p["observations"][1:] - nobs_o[k][:-1]).max() < 1e-10), what
+        assert np.array_equal(p["env_infos"]["state"]["timestep"], t0 + np.arange(H)) and len(p["states"]) == H, what

@@ -72,6 +72,10 @@ struct FilterCoefs {
 template <class T, int NV>
 __global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restrict__ raw, int K, int H, FilterCoefs fc,
                                                           int filter, T* __restrict__ eps) {
+    // numpy rounds every product and every sum of the recursion by itself; the compiler must not fuse them (it did:
+    // with the reference's usual taps (0.25, 0.8, 0) a fused multiply-add gives the same bits -- 0.25 e is exact, 0 e2
+    // vanishes -- so only other coefficients showed the last-bit difference)
+#pragma clang fp contract(off)
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= K) return;
     raw += (size_t)blockIdx.y * K * H * NV;           // planner blockIdx.y of a batched handle
@@ -84,8 +88,10 @@ __global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restri
         for (int j = 0; j < NV; j++) {
             double e = raw[((size_t)k * H + t) * NV + j];
             if (filter) {
-                e = __dmul_rn(e, fc.sigma[j]);
-                if (t >= 2) e = __dadd_rn(__dadd_rn(__dmul_rn(fc.b0, e), __dmul_rn(fc.b1, e1[j])), __dmul_rn(fc.b2, e2[j]));
+                // (plain operators: the rounding intrinsics are inline functions compiled with contraction allowed,
+                // which the pragma above cannot reach)
+                e = e * fc.sigma[j];
+                if (t >= 2) e = (fc.b0 * e + fc.b1 * e1[j]) + fc.b2 * e2[j];
             }
             e2[j] = e1[j];
             e1[j] = e;

@@ -300,3 +300,47 @@ def test_random_configurations_of_gather_paths_parallel(oracle_sim, case):
         assert np.abs(p["rewards"] - rew_o[k]).max() < 1e-10 * (1 + np.abs(rew_o[k]).max()), what
         assert p["observations"].shape == (H, 20) and (H == 1 or np.abs(p["observations"][1:] - nobs_o[k][:-1]).max() < 1e-10), what
         assert np.array_equal(p["env_infos"]["state"]["timestep"], t0 + np.arange(H)) and len(p["states"]) == H, what
+
+
+@pytest.mark.parametrize("case", range(max(2 * WALKS, 8)))
+def test_random_shapes_of_the_update(case):
+    """The planner's update (maximum, first arg-max, weights, weighted sums; the launch shape changes with K, H and
+    the number of planners) over random sample counts from one to 150 000, horizons, planners per handle and kappa from
+    0 to 300, against the numpy update of the device's own returns and actions; and `mppi_update_from_returns` for
+    caller-supplied (actions, returns) of random shape."""
+    from trajopt_amd.device import DeviceModel, DevicePlanner, update_from_returns
+    rs = np.random.RandomState(999 + case)
+    dm = DeviceModel.get("reacher_7dof")
+    H = int(rs.randint(1, 33))
+    P = int(rs.choice([1, 1, 1, 2, 5]))
+    kmax = min(150000, 2_000_000 // (H * P))
+    K = int(np.exp(rs.uniform(0, np.log(kmax))))
+    kappa = float(rs.choice([0.0, 1.0, 25.0, 300.0]))
+    dtype = str(rs.choice(["f32", "f64"]))
+    lead = (P,) if P > 1 else ()
+    p = DevicePlanner(dm, K, H, kappa=kappa, gamma=float(rs.choice([1.0, 0.9])), sigma=np.ones(7), betas=(0.25, 0.8, 0.0),
+                      dtype=dtype, planners=P, default_act="mean")
+    p.set_start_state(0.3 * rs.randn(*lead, 7), rs.randn(*lead, 7), rs.uniform(-0.2, 0.2, lead + (3,)), 0)
+    base = 0.3 * rs.randn(*lead, H, 7)
+    p.set_base_actions(base)
+    p.generate_noise(int(rs.randint(1, 10 ** 6)))
+    act = p.actions().reshape(P, K, H, 7)             # (read before the update moves the base they are relative to)
+    p.iterate(1)
+    R, seq = p.returns().reshape(P, K), p.act_sequence().reshape(P, H, 7)
+    am, rmax = np.atleast_1d(p.argmax()), np.atleast_1d(p.rmax())
+    what = (case, K, H, P, kappa, dtype)
+    assert p.status() == 0, what
+    for b in range(P):
+        want = ref_mppi.update(act[b], R[b].astype(np.float64), kappa)
+        # (an fp32 planner reports the fp32 actions its rollouts used; the update sums the perturbations in fp64)
+        tol = 1e-9 if dtype == "f64" else 1e-6
+        assert np.abs(seq[b] - want).max() < tol * (1 + np.abs(want).max()), (what, b, np.abs(seq[b] - want).max())
+        assert int(am[b]) == int(np.argmax(R[b])) and rmax[b] == R[b].max(), (what, b)
+    p.close()
+    # caller-supplied paths
+    K2, HM = int(np.exp(rs.uniform(0, np.log(60000)))), int(rs.randint(1, 300))
+    K2 = min(K2, 3_000_000 // HM)
+    A, R2 = rs.randn(K2, HM), rs.randn(K2) * rs.choice([0.01, 1.0, 50.0])
+    got = update_from_returns(A.reshape(K2, HM, 1), R2, kappa).reshape(HM)
+    want = ref_mppi.update(A, R2, kappa)
+    assert np.abs(got - want).max() < 1e-11 * (1 + np.abs(want).max()), (what, K2, HM)

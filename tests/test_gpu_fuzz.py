@@ -344,3 +344,71 @@ def test_random_shapes_of_the_update(case):
     got = update_from_returns(A.reshape(K2, HM, 1), R2, kappa).reshape(HM)
     want = ref_mppi.update(A, R2, kappa)
     assert np.abs(got - want).max() < 1e-11 * (1 + np.abs(want).max()), (what, K2, HM)
+
+
+@pytest.mark.parametrize("walk", range(max(WALKS, 4)))
+def test_random_walk_over_the_environment(reacher_model, walk):
+    """`Reacher7DOFEnv` (steps on the device, site positions computed when somebody looks) against the oracle's twin of
+    the reference class through random sequences of reset_model / step / set_env_state / set_state / sim.forward /
+    target_reset and reads of the observation, the state dict and `data.site_xpos` at random moments: 1e-10."""
+    from oracle.ref_rollout import OracleReacherEnv
+    from trajopt.envs.utils import get_environment
+    rs = np.random.RandomState(31337 + walk)
+    rt = str(rs.choice(["dense", "sparse", "tracking", "cooling"]))
+    reference = np.cumsum(0.004 * rs.randn(400, 3), axis=0) + np.array([0.6, -0.3, 0.2]) if rt in ("tracking", "cooling") else None
+    e = get_environment('reacher_7dof', reward_type=rt, reference=reference)
+    o = OracleReacherEnv(reacher_model, reward_type=rt, reference=reference)
+    e.reset_model(goal=(0.1, 0.0, 0.1), alpha=0.7)
+    o.reset_model(goal=(0.1, 0.0, 0.1), alpha=0.7)
+    trace = []
+
+    def same():
+        where = "%s: %s" % (rt, " | ".join(trace[-12:]))
+        look = rs.randint(4)
+        if look == 0:
+            assert np.abs(e._get_obs() - o._get_obs()).max() < 1e-10, where
+        elif look == 1:
+            assert np.abs(e.data.site_xpos[e.hand_sid] - o.hand).max() < 1e-10 and np.abs(e.data.site_xpos[e.target_sid] - o.target).max() < 1e-12, where
+        elif look == 2:
+            se, so = e.get_env_state(), o.get_env_state()
+            assert np.abs(se["qp"] - so["qp"]).max() < 1e-10 and np.abs(se["qv"] - so["qv"]).max() < 1e-10, where
+            assert np.array_equal(se["target_pos"], so["target_pos"]) and se["timestep"] == so["timestep"], where
+        # (look == 3: nobody looks -- the lazy site positions must still be right at the next look)
+
+    for _ in range(60):
+        op = rs.randint(8)
+        if op <= 2:
+            if e.env_timestep > 300:
+                continue
+            a = rs.randn(7) * rs.choice([0.3, 1.0, 3.0])
+            ob, r, done, info = e.step(a)
+            ob_o, r_o, _, info_o = o.step(a)
+            trace.append("step")
+            assert np.abs(ob - ob_o).max() < 1e-10 and abs(r - r_o) < 1e-10 * (1 + abs(r_o)) and done is False, (rt, trace[-12:])
+            assert info["state"]["timestep"] == info_o["state"]["timestep"]
+        elif op == 3:
+            s = dict(qp=rs.uniform(-1, 1, 7) * np.array([1, 0.5, 1, 1, 1, 0.5, 1]), qv=rs.randn(7), target_pos=rs.uniform(-0.2, 0.2, 3),
+                     timestep=int(rs.randint(0, 100)))
+            e.set_env_state(s); o.set_env_state(s)
+            trace.append("set_env_state")
+        elif op == 4:
+            g, al = rs.uniform(-0.2, 0.2, 3), float(rs.choice([1.0, 0.3]))
+            ob, ob_o = e.reset_model(goal=g, alpha=al), o.reset_model(goal=g, alpha=al)
+            trace.append("reset_model")
+            assert np.abs(ob - ob_o).max() < 1e-10, (rt, trace[-12:])
+        elif op == 5:
+            q, v = rs.uniform(-1, 1, 7) * 0.5, rs.randn(7)
+            e.set_state(q, v)
+            o.qpos, o.qvel, o.hand = q.copy(), v.copy(), o.sim.fk_hand(q)
+            trace.append("set_state")
+        elif op == 6:
+            e.sim.forward()
+            o.hand = o.sim.fk_hand(o.qpos)
+            trace.append("forward")
+        else:
+            g = rs.uniform(-0.2, 0.2, 3)
+            e.target_reset(g)
+            o.target = np.array(g)
+            o.hand = o.sim.fk_hand(o.qpos)         # target_reset ends in sim.forward()
+            trace.append("target_reset")
+        same()

@@ -412,3 +412,69 @@ def test_random_walk_over_the_environment(reacher_model, walk):
             o.hand = o.sim.fk_hand(o.qpos)         # target_reset ends in sim.forward()
             trace.append("target_reset")
         same()
+
+
+@pytest.mark.parametrize("case", range(max(WALKS, 4)))
+def test_random_shardings_of_one_planner(case):
+    """A planner's samples cut into shards of random sizes (global sample index = the shard's offset + the local one, so
+    the Philox stream does not depend on the cut): every shard's returns are its slice of the unsharded planner's, and
+    the merged statistics give the unsharded act_sequence, arg-max and maximum on every shard -- over several planning
+    steps, with the real environment stepped on every shard alike.  Cuts at multiples of 64 keep every wavefront's
+    samples together and reproduce the returns bit for bit; a ragged cut regroups samples into other wavefronts, and a
+    sample's active-set solve runs as many sweeps as its slowest wave-mate needs (a repeated sweep solves the same set
+    again through the other factorisation routine), so its returns then agree to rounding, not to the bit."""
+    import torch
+    from trajopt_amd.device import DeviceModel, DevicePlanner
+    from trajopt_amd import sharding
+    rs = np.random.RandomState(2718 + case)
+    dm = DeviceModel.get("reacher_7dof")
+    K, H = int(rs.randint(2, 3000)), int(rs.randint(2, 20))
+    aligned = case % 2 == 0 and K > 128
+    G = int(rs.randint(2, min(6, K // 64 if aligned else K) + 1))
+    cuts = np.sort(rs.choice(np.arange(64, K, 64) if aligned else np.arange(1, K), size=G - 1, replace=False))
+    lo, hi = np.r_[0, cuts], np.r_[cuts, K]
+    dtype, kappa, seed = str(rs.choice(["f32", "f64"])), float(rs.choice([1.0, 25.0])), int(rs.randint(1, 10 ** 6))
+    q0, v0, tgt = 0.3 * rs.randn(7), rs.randn(7), rs.uniform(-0.2, 0.2, 3)
+
+    def make(k, off):
+        p = DevicePlanner(dm, k, H, kappa=kappa, sigma=np.ones(7), betas=(0.25, 0.8, 0.0), dtype=dtype, default_act="mean", k_offset=off)
+        p.set_start_state(q0, v0, tgt, 0)
+        p.set_base_actions(np.zeros((H, 7)))
+        return p
+    full = make(K, 0)
+    shards = [make(int(hi[g] - lo[g]), int(lo[g])) for g in range(G)]
+    what = (case, K, H, list(map(int, cuts)), dtype)
+    for step in range(3):
+        full.generate_noise_step(seed); full.iterate(1)
+        R, want = full.returns(), full.act_sequence()
+        for s in shards:
+            s.generate_noise_step(seed); s.local_partials(); s.synchronize()
+        for g, s in enumerate(shards):
+            if aligned:
+                assert np.array_equal(s.returns(), R[lo[g]:hi[g]]), (what, step, g)
+            else:
+                d = np.abs(s.returns() - R[lo[g]:hi[g]]).max() / np.abs(R).max()
+                assert d < (1e-10 if dtype == "f64" else 2e-4), (what, step, g, d)
+        rows = np.stack([s.partials() for s in shards])
+        gathered = torch.from_numpy(rows).cuda()
+        torch.cuda.synchronize()
+        host = sharding.merge_rows(rows, np.zeros((H, 7)) if step == 0 else base_before, kappa)
+        for s in shards:
+            s.merge(gathered.data_ptr(), G)
+            tol = 1e-11 if aligned else (1e-8 if dtype == "f64" else 5e-2)      # (kappa (R - Rmax) in the exponent)
+            assert np.abs(s.act_sequence() - want).max() < tol * (1 + np.abs(want).max()), (what, step)
+            if aligned:
+                assert s.argmax() == full.argmax() and s.rmax() == full.rmax(), (what, step)
+        assert np.abs(host[0] - shards[0].act_sequence()).max() < 1e-11 * (1 + np.abs(want).max()), (what, step)
+        full.advance()
+        for s in shards:
+            s.advance()
+        base_before = full.act_sequence()
+        for s in shards:                              # the shards drift apart from the full planner only in rounding
+            assert np.abs(s.act_sequence() - base_before).max() < (1e-10 if aligned else (1e-7 if dtype == "f64" else 0.5)), (what, step)
+            s.set_base_actions(base_before)           # ... which this test removes, to compare the next step exactly
+            lf, ls = full.read_log(max_rows=1), s.read_log(max_rows=1)
+            assert np.abs(ls["qpos"] - lf["qpos"]).max() < (1e-9 if aligned or dtype == "f64" else 1e-2), (what, step)
+            s.set_start_state(lf["qpos"][0], lf["qvel"][0], tgt, step + 1)
+    for p in [full] + shards:
+        p.close()

@@ -10,7 +10,9 @@ import torch.distributed as dist
 
 def shard_range(K_global, rank, world):
     """Contiguous shard [lo, hi) of rank; K_global must divide evenly so that every rank
-    launches the same grid."""
+    launches the same grid.  Shards that are multiples of 64 samples keep every wavefront's samples together and
+    reproduce the unsharded returns bit for bit; other sizes regroup samples into other wavefronts, whose active-set
+    solves run as many sweeps as their slowest sample needs, and reproduce them to rounding."""
     if K_global % world:
         raise ValueError("K=%d is not divisible by %d ranks" % (K_global, world))
     per = K_global // world

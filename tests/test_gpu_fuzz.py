@@ -478,3 +478,61 @@ def test_random_shardings_of_one_planner(case):
             s.set_start_state(lf["qpos"][0], lf["qvel"][0], tgt, step + 1)
     for p in [full] + shards:
         p.close()
+
+
+@pytest.mark.parametrize("case", range(max(2 * WALKS, 8)))
+def test_reference_boundaries_raise_where_the_reference_raises(reacher_model, case):
+    """Tracking / cooling rewards index the reference trajectory with the time step after every env step
+    (trajopt/envs/reacher_env.py:61,75): a rollout of H steps from time step t reads rows t + 1 .. t + H and raises
+    IndexError when the trajectory is shorter; a missing reference raises TypeError.  Random (t, H, length) around the
+    boundary through `do_env_rollout`, `gather_paths_parallel`, `env.step` and `MPPI.train_step`, against the oracle's
+    twin of the reference code (which raises from numpy's own indexing)."""
+    from oracle import ref_rollout
+    from trajopt import utils
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    rs = np.random.RandomState(555 + case)
+    rt = str(rs.choice(["tracking", "cooling"]))
+    t0, H = int(rs.randint(0, 20)), int(rs.randint(1, 12))
+    n = t0 + H + int(rs.randint(-2, 3))
+    reference = (np.cumsum(0.01 * rs.randn(max(n, 1), 3), axis=0) + np.array([0.6, -0.3, 0.2]))[:max(n, 0)]
+    s = dict(qp=0.2 * rs.randn(7), qv=rs.randn(7), target_pos=rs.uniform(-0.1, 0.1, 3), timestep=t0)
+    acts = [0.5 * rs.randn(H, 7) for _ in range(3)]
+    what = (case, rt, t0, H, n)
+
+    def outcome(f):
+        try:
+            return ("ok", f())
+        except (IndexError, TypeError) as ex:
+            return (type(ex).__name__, None)
+    want = outcome(lambda: ref_rollout.do_env_rollout(reacher_model, s, acts, None, rt, reference, 0.5))
+    got = outcome(lambda: utils.do_env_rollout('reacher_7dof', s, acts, None, rt, reference, 0.5))
+    assert got[0] == want[0] == ("ok" if n > t0 + H else "IndexError"), (what, got[0], want[0])
+    if got[0] == "ok":
+        for pw, pg in zip(want[1], got[1]):
+            assert np.abs(pg["rewards"] - pw["rewards"]).max() < 2e-3 * (1 + np.abs(pw["rewards"]).max()), what      # fp32 rollouts
+    got = outcome(lambda: utils.gather_paths_parallel('reacher_7dof', s, acts[0], FILTER, 7, None, rt, reference, 0.5, 4, 2))
+    assert got[0] == want[0], (what, got[0])
+    # no reference at all: indexing None
+    assert outcome(lambda: utils.do_env_rollout('reacher_7dof', s, acts, None, rt, None, 0.5))[0] == "TypeError", what
+    # one real step needs row t + 1 only; the constructor itself takes one from time step 0 (trajopt/envs/mujoco_env.py:53)
+    if n <= 1:
+        assert outcome(lambda: get_environment('reacher_7dof', reward_type=rt, reference=reference))[0] == "IndexError", what
+        return
+    e = get_environment('reacher_7dof', reward_type=rt, reference=reference)
+    e.reset_model(goal=s["target_pos"], alpha=0.5)
+    e.set_env_state(s)
+    o = ref_rollout.OracleReacherEnv(reacher_model, reward_type=rt, reference=reference)
+    o.reset_model(goal=s["target_pos"], alpha=0.5)
+    o.set_env_state(s)
+    a, b = outcome(lambda: e.step(acts[0][0])), outcome(lambda: o.step(acts[0][0]))
+    assert a[0] == b[0] == ("ok" if n > t0 + 1 else "IndexError"), (what, a[0], b[0])
+    if a[0] == "ok":
+        assert abs(a[1][1] - b[1][1]) < 1e-10
+    # the planner: rollouts from the agent's state need t + H, checked before anything is launched
+    e.set_env_state(s)
+    ag = MPPI(e, H=H, paths_per_cpu=8, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=3, reward_type=rt, reference=reference)
+    before = len(ag.sol_state)
+    got = outcome(lambda: ag.train_step(niter=1))
+    assert got[0] == ("ok" if n > t0 + H else "IndexError"), (what, got[0])
+    assert len(ag.sol_state) == before + (got[0] == "ok"), what

@@ -37,6 +37,9 @@ class DeviceModel:
         qpos, qvel, target, act = L.f64(qpos), L.f64(qvel), L.f64(target), L.f64(act)
         assert qpos.shape == (nq,) and qvel.shape == (nv,) and act.shape == (nv,) and target.shape == (3,)
         ref = None if reference is None else L.f64(reference)
+        if ref is not None and len(ref) == 0 and reward_type in ("tracking", "cooling"):
+            # an empty trajectory is still a trajectory: indexing it raises IndexError in the reference
+            raise IndexError("index %d is out of bounds for the reference trajectory" % (timestep + 1))
         q2, v2, obs = np.empty(nq), np.empty(nv), np.empty(nq + nv + 6)
         r = C.c_double(0.0)
         rc = L.lib().mppi_env_step(self._h, default_device() if device is None else device, L.ptr(qpos), L.ptr(qvel),

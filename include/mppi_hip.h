@@ -245,6 +245,9 @@ int mppi_plan(mppi_planner* p, uint64_t seed, int32_t niter, int32_t nsteps, voi
  * { generate_noise_step; iterate; advance; }*.  No counterpart in the reference (its noise is drawn
  * inside every worker, trajopt/utils.py:135-139). */
 int mppi_advance_noise(mppi_planner* p, uint64_t seed, void* stream);
+/* The status word (MPPI_READ_STATUS) is sticky: a bit stays set until it is cleared here.  No counterpart in the
+ * reference (its simulator prints a warning and carries on). */
+int mppi_clear_status(mppi_planner* p);
 int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* total);
 /* What one `MPPI.train_step` hands back to its caller (trajopt/algos/mppi.py:74-89), after mppi_advance,
  * mppi_advance_noise or mppi_plan: the newest log row of every planner (P x (3M+7) doubles, layout as in

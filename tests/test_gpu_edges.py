@@ -361,4 +361,11 @@ def test_diverged_rollouts_take_no_part_in_the_update(dm, oracle_sim, dtype):
     want = ref_mppi.update(act[~bad], R[~bad].astype(np.float64), 25.0)
     assert np.abs(seq - want).max() < (1e-9 if dtype == "f64" else 1e-6)
     assert p.argmax() == int(np.flatnonzero(~bad)[np.argmax(R[~bad])])
+    # the status word is sticky until cleared: a clean rollout afterwards leaves the bit, clear_status removes it
+    p.set_start_state(np.zeros(7), np.zeros(7), np.array([0.1, 0.0, 0.2]), 0)
+    p.rollout()
+    assert np.isfinite(p.returns()).all() and p.status() & 1
+    p.clear_status()
+    p.rollout()
+    assert p.status() == 0
     p.close()

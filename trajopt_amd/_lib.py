@@ -62,6 +62,7 @@ _PROTOS = {
     "mppi_set_reference": (C.c_int, [_vp, _vp, _i32, _d]),
     "mppi_set_params": (C.c_int, [_vp, _d, _d, _i32]),
     "mppi_set_env_reward": (C.c_int, [_vp, _i32]),
+    "mppi_clear_status": (C.c_int, [_vp]),
     "mppi_set_critic": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, C.c_float]),
     "mppi_upload_noise": (C.c_int, [_vp, _vp, _vp]),
     "mppi_host_staging": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),

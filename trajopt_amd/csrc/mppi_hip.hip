@@ -1243,6 +1243,17 @@ int mppi_profile_read(mppi_planner* p, double* rollout_ms_total, int32_t* launch
     return fail(-8, std::string("host exception: ") + e.what());
 }
 
+// The status word is sticky: bits stay set until this call (enqueued on the planner's stream, behind whatever may
+// still set them).
+int mppi_clear_status(mppi_planner* p) try {
+    if (!p) return fail(-1, "null argument");
+    HIP_OK(hipSetDevice(p->cfg.device));
+    HIP_OK(hipMemsetAsync(p->d_status, 0, 16, p->stream));
+    return 0;
+} catch (const std::exception& e) {
+    return fail(-8, std::string("host exception: ") + e.what());
+}
+
 int mppi_synchronize(mppi_planner* p) try {
     if (!p) return fail(-1, "null argument");
     HIP_OK(hipSetDevice(p->cfg.device));

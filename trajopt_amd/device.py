@@ -330,6 +330,10 @@ class DevicePlanner:
     def status(self):
         return int(self._read(L.READ_STATUS, (1,), np.int32)[0])
 
+    def clear_status(self):
+        """The status word is sticky; this clears it (behind the work already enqueued)."""
+        L.check(L.lib().mppi_clear_status(self._h))
+
     def status_detail(self):
         """(bits, first sample of the wave + 1, env step, planner) of the first capped solve a general-variant rollout reported."""
         return [int(x) for x in self._read(L.READ_STATUS_DETAIL, (4,), np.int32)]

@@ -536,3 +536,43 @@ def test_reference_boundaries_raise_where_the_reference_raises(reacher_model, ca
     got = outcome(lambda: ag.train_step(niter=1))
     assert got[0] == ("ok" if n > t0 + H else "IndexError"), (what, got[0])
     assert len(ag.sol_state) == before + (got[0] == "ok"), what
+
+
+@pytest.mark.parametrize("case", range(max(WALKS, 4)))
+def test_random_critics_against_torch(oracle_sim, case):
+    """The terminal-value kernel (matrix cores, hardware exponentials) for random input slices, sample counts (ragged
+    last blocks), discounts and weight scales from tiny to saturating, against torch's fp32 module on the oracle's final
+    observations: within 2e-5 of the value range (fp64 rollouts, so only the network differs)."""
+    import torch
+    from trajopt.models.critic_nets import Critic
+    from trajopt_amd.algos.mppi import _critic_weights
+    from trajopt_amd.device import DeviceModel, DevicePlanner
+    rs = np.random.RandomState(8080 + case)
+    dim = int(rs.choice([14, 15, 17, 3, 6]))
+    K, H, gamma = int(rs.randint(1, 1500)), int(rs.randint(1, 9)), float(rs.choice([1.0, 0.9]))
+    torch.manual_seed(case)
+    critic = Critic(input_dim=dim)
+    scale = float(rs.choice([0.01, 1.0, 8.0]))          # 8: most hidden units saturate
+    with torch.no_grad():
+        critic.linear1.weight.mul_(scale); critic.linear2.weight.mul_(scale)
+        critic.linear3.weight.mul_(float(rs.choice([1.0, 40.0])))
+    goal, q0 = rs.uniform(-0.2, 0.2, 3), 0.4 * rs.randn(7) * np.array([1, 0.5, 1, 1, 1, 0.5, 1])
+    raw = rs.randn(K, H, 7)
+    p = DevicePlanner(DeviceModel.get("reacher_7dof"), K, H, kappa=5.0, gamma=gamma, sigma=FILTER[0], betas=FILTER[1:], dtype="f64")
+    p.set_start_state(q0, np.zeros(7), goal, 0)
+    p.set_base_actions(np.zeros((H, 7)))
+    p.upload_noise(raw)
+    p.set_critic(dim, _critic_weights(critic, dim))
+    p.rollout()
+    R = p.returns()
+    _, nobs, rew = oracle_sim.rollout(q0, np.zeros(7), goal, 0, ref_mppi.filter_noise(raw.copy(), FILTER), gamma=gamma, dump=True)
+    obs = torch.tensor(nobs[:, -1], dtype=torch.float32)
+    x = {14: obs[:, :14], 15: torch.cat((obs[:, :14], torch.linalg.norm(obs[:, -6:-3] - obs[:, -3:], dim=1, keepdim=True)), 1),
+         17: torch.cat((obs[:, :14], obs[:, -3:]), 1), 3: obs[:, -6:-3], 6: obs[:, -6:]}[dim]
+    with torch.no_grad():
+        V = critic(x).numpy().reshape(-1).astype(np.float64)
+    want = (rew[:, :-1] * gamma ** np.arange(H - 1)).sum(1) + gamma ** (H - 1) * V
+    span = max(np.abs(V).max(), 1.0)
+    assert np.abs(R - want).max() < 2e-5 * span, (case, dim, K, H, scale, np.abs(R - want).max(), span)
+    assert p.status() == 0
+    p.close()

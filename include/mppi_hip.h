@@ -17,7 +17,9 @@
  * torch tensor's data_ptr()): the library looks the address up and copies from
  * where it lies.  `stream` arguments take a hipStream_t (or NULL for the
  * planner's own stream).  A planner is not re-entrant; distinct planners may
- * be driven from distinct host threads.  A model handle may be shared between
+ * be driven from distinct host threads (the library keeps off the legacy
+ * stream, which the runtime blocks for the whole process while any thread
+ * captures a graph).  A model handle may be shared between
  * threads: mppi_env_step / mppi_env_forward calls on one model and device take
  * turns inside the library (their own stream, no device-wide synchronisation).
  */

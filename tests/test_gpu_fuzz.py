@@ -576,3 +576,48 @@ def test_random_critics_against_torch(oracle_sim, case):
     assert np.abs(R - want).max() < 2e-5 * span, (case, dim, K, H, scale, np.abs(R - want).max(), span)
     assert p.status() == 0
     p.close()
+
+
+def test_planners_driven_from_several_host_threads():
+    """Distinct planners may be driven from distinct host threads (ctypes releases the interpreter lock inside every
+    call): four threads, each planning and reading back step by step on planners of its own -- device noise, host
+    noise drawn by the library, different sizes, several planner lifetimes per thread, so that one thread allocates,
+    fills and reads while another captures its graphs -- give what the same planners give one after the other.
+    (The captures are made in relaxed mode: a capture in thread-local mode made every allocation-time fill and every
+    synchronous read of the other threads fail, and spoiled the capture too.)"""
+    import threading
+    from trajopt_amd.device import DeviceModel, DevicePlanner
+    from trajopt_amd.utils import worker_seeds
+    dm = DeviceModel.get("reacher_7dof")
+    specs = [(4096, 16, "f32", "philox"), (300, 8, "f64", "philox"), (512, 12, "f32", "host"), (64, 20, "f64", "host")]
+
+    def run(spec, out, idx):
+        K, H, dtype, noise = spec
+        rows, status = [], 0
+        for life in range(5):
+            p = DevicePlanner(dm, K, H, kappa=25.0, sigma=FILTER[0], betas=FILTER[1:], mean=np.zeros(7), default_act="mean", dtype=dtype)
+            p.set_start_state(np.full(7, 0.1 * idx + 0.02 * life), np.zeros(7), np.array([0.1, 0.0, 0.1]), 0)
+            p.set_base_actions(np.zeros((H, 7)))
+            for t in range(16):
+                if noise == "philox":
+                    p.plan(11 + idx, 1 + life % 2, 1 if t % 5 else 9)       # (a run of nine captures a second graph)
+                else:
+                    p.draw_noise(worker_seeds(1000 * idx + t, K // 2, 2), 2)
+                    p.commit_noise(); p.iterate(1 + life % 2); p.advance()
+                row, seq = p.read_step()
+                rows.append(np.r_[row, seq.ravel(), p.returns()[:4], p.read_log(max_rows=1)["reward"]])
+            status |= p.status()
+            p.close()
+        out[idx] = (np.array(rows), status)
+
+    serial, threaded = {}, {}
+    for i, spec in enumerate(specs):
+        run(spec, serial, i)
+    threads = [threading.Thread(target=run, args=(spec, threaded, i)) for i, spec in enumerate(specs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(len(specs)):
+        assert threaded[i][1] == serial[i][1] == 0
+        assert np.array_equal(threaded[i][0], serial[i][0]), i

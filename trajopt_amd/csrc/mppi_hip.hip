@@ -355,6 +355,19 @@ static void set_eps_source(mppi_planner* p, bool philox) {
     p->eps_philox = philox;
 }
 
+// Synchronous copies and fills, made on a stream of the caller's and waited for there.  Never on the legacy (null)
+// stream: while any thread of the process captures a graph, the runtime refuses every operation on the legacy stream
+// ("would make the legacy stream depend on a capturing ... stream") and spoils that capture too, so planners driven
+// from different host threads would break each other at allocation and read-back time.
+static hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+static hipError_t zero_now(void* dst, size_t bytes, hipStream_t s) {
+    const hipError_t e = hipMemsetAsync(dst, 0, bytes, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+
 // Input arrays may be host memory or device memory (a torch tensor's data_ptr()): bulk copies use hipMemcpyDefault,
 // which takes the direction from the addresses; the few small arrays the host itself has to look at come through here.
 static bool on_device(const void* ptr) {
@@ -365,10 +378,10 @@ static bool on_device(const void* ptr) {
     }
     return a.type == hipMemoryTypeDevice;
 }
-static int host_view(const double* src, size_t n, std::vector<double>& tmp, const double** out) {
+static int host_view(const double* src, size_t n, std::vector<double>& tmp, const double** out, hipStream_t s) {
     if (!on_device(src)) { *out = src; return 0; }
     tmp.resize(n);
-    HIP_OK(hipMemcpy(tmp.data(), src, n * 8, hipMemcpyDeviceToHost));
+    HIP_OK(copy_now(tmp.data(), src, n * 8, hipMemcpyDeviceToHost, s));
     *out = tmp.data();
     return 0;
 }
@@ -403,31 +416,31 @@ static int planner_allocate(mppi_planner* p) {
     const size_t K = cfg->K * P, HM = p->HM * P, OD = p->nq + p->nv + 6;   // sizes over all planners
     HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_OK(hipMalloc(&p->d_state, sizeof(DevState) * P));
-    HIP_OK(hipMemset(p->d_state, 0, sizeof(DevState) * P));
+    HIP_OK(zero_now(p->d_state, sizeof(DevState) * P, p->stream));
     HIP_OK(hipMalloc(&p->d_base, HM * 8));
     HIP_OK(hipMalloc(&p->d_base_tmp, HM * 8));
     HIP_OK(hipMalloc(&p->d_mean, MPPI_MAXV * 8));
-    HIP_OK(hipMemcpy(p->d_mean, cfg->mean, MPPI_MAXV * 8, hipMemcpyHostToDevice));
+    HIP_OK(copy_now(p->d_mean, cfg->mean, MPPI_MAXV * 8, hipMemcpyHostToDevice, p->stream));
     HIP_OK(hipMalloc(&p->d_eps, (size_t)p->HM * K * p->esz));
-    HIP_OK(hipMemset(p->d_eps, 0, (size_t)p->HM * K * p->esz));
+    HIP_OK(zero_now(p->d_eps, (size_t)p->HM * K * p->esz, p->stream));
     HIP_OK(hipMalloc(&p->d_R, K * p->esz));
-    HIP_OK(hipMemset(p->d_R, 0, K * p->esz));
+    HIP_OK(zero_now(p->d_R, K * p->esz, p->stream));
     HIP_OK(hipMalloc(&p->d_part, (3 * P + HM) * 8));
-    HIP_OK(hipMemset(p->d_part, 0, (3 * P + HM) * 8));
+    HIP_OK(zero_now(p->d_part, (3 * P + HM) * 8, p->stream));
     HIP_OK(hipMalloc(&p->d_result, 2 * 8 * P));
-    HIP_OK(hipMemset(p->d_result, 0, 2 * 8 * P));
+    HIP_OK(zero_now(p->d_result, 2 * 8 * P, p->stream));
     if (update_wants_weights(cfg->K, cfg->H, (int)P)) HIP_OK(hipMalloc(&p->d_weights, P * ((size_t)cfg->K + 2) * 8));
     HIP_OK(hipMalloc(&p->d_status, 16));
-    HIP_OK(hipMemset(p->d_status, 0, 16));
+    HIP_OK(zero_now(p->d_status, 16, p->stream));
     HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (p->nq + 2 * p->nv + 7) * 8));
     HIP_OK(hipMalloc(&p->d_log_count, 4 * P));
-    HIP_OK(hipMemset(p->d_log_count, 0, 4 * P));
+    HIP_OK(zero_now(p->d_log_count, 4 * P, p->stream));
     HIP_OK(hipMalloc(&p->d_next_step, 4 * P));
-    HIP_OK(hipMemset(p->d_next_step, 0, 4 * P));
+    HIP_OK(zero_now(p->d_next_step, 4 * P, p->stream));
     HIP_OK(hipMalloc(&p->d_noise_key, 8 * P));
-    HIP_OK(hipMemset(p->d_noise_key, 0, 8 * P));
+    HIP_OK(zero_now(p->d_noise_key, 8 * P, p->stream));
     HIP_OK(hipMalloc(&p->d_last_row, P * (p->nq + 2 * p->nv + 7) * 8));
-    HIP_OK(hipMemset(p->d_last_row, 0, P * (p->nq + 2 * p->nv + 7) * 8));
+    HIP_OK(zero_now(p->d_last_row, P * (p->nq + 2 * p->nv + 7) * 8, p->stream));
     HIP_OK(hipHostMalloc(&p->h_step, (P * (p->nq + 2 * p->nv + 7) + HM) * 8, hipHostMallocDefault));
     if (P == 1) {
         const size_t n = (size_t)(p->nq + 2 * p->nv + 7) + p->HM + 1;
@@ -443,7 +456,7 @@ static int planner_allocate(mppi_planner* p) {
     std::vector<double> base(HM);
     for (size_t t = 0; t < (size_t)cfg->H * P; t++)
         for (int j = 0; j < p->nv; j++) base[t * p->nv + j] = cfg->mean[j];
-    HIP_OK(hipMemcpy(p->d_base, base.data(), HM * 8, hipMemcpyHostToDevice));
+    HIP_OK(copy_now(p->d_base, base.data(), HM * 8, hipMemcpyHostToDevice, p->stream));
     for (int j = 0; j < MPPI_MAXV; j++) p->fc.sigma[j] = cfg->sigma[j];
     p->fc.b0 = cfg->beta[0]; p->fc.b1 = cfg->beta[1]; p->fc.b2 = cfg->beta[2];
     return 0;
@@ -572,12 +585,12 @@ int mppi_set_start_state(mppi_planner* p, const double* qpos, const double* qvel
     HIP_OK(hipSetDevice(p->cfg.device));
     // alpha / ref_len come from the host mirror; q, v, target, timestep are replaced
     std::vector<double> tq, tv, tt;
-    int rc = host_view(qpos, (size_t)p->P * p->nq, tq, &qpos);
-    if (!rc) rc = host_view(qvel, (size_t)p->P * p->nv, tv, &qvel);
-    if (!rc) rc = host_view(target3, (size_t)p->P * 3, tt, &target3);
+    int rc = host_view(qpos, (size_t)p->P * p->nq, tq, &qpos, p->stream);
+    if (!rc) rc = host_view(qvel, (size_t)p->P * p->nv, tv, &qvel, p->stream);
+    if (!rc) rc = host_view(target3, (size_t)p->P * 3, tt, &target3, p->stream);
     if (rc) return rc;
     std::vector<int32_t> ts(p->P);
-    if (on_device(timestep)) HIP_OK(hipMemcpy(ts.data(), timestep, (size_t)p->P * 4, hipMemcpyDeviceToHost));
+    if (on_device(timestep)) HIP_OK(copy_now(ts.data(), timestep, (size_t)p->P * 4, hipMemcpyDeviceToHost, p->stream));
     else std::memcpy(ts.data(), timestep, (size_t)p->P * 4);
     timestep = ts.data();
     std::vector<DevState>& s = *p->h_state;
@@ -651,7 +664,7 @@ int mppi_set_critic(mppi_planner* p, int32_t dim, int32_t inner, const float* W1
     pack_critic_weights(dim, W1, b1, W2, b2, W3, b3, w.data());
     if (!p->d_critic) HIP_OK(hipMalloc(&p->d_critic, CRITIC_W_FLOATS * 4));
     if (!p->d_fobs) HIP_OK(hipMalloc(&p->d_fobs, (size_t)p->cfg.K * p->P * (p->nq + p->nv + 6) * p->esz));
-    HIP_OK(hipMemcpy(p->d_critic, w.data(), CRITIC_W_FLOATS * 4, hipMemcpyHostToDevice));
+    HIP_OK(copy_now(p->d_critic, w.data(), CRITIC_W_FLOATS * 4, hipMemcpyHostToDevice, p->stream));
     if (p->critic_dim != dim) p->cfg_gen++;       // the weights are read at run time; the input slice is an argument
     p->critic_dim = dim;
     return 0;
@@ -827,7 +840,7 @@ int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_ro
     HIP_OK(hipSetDevice(p->cfg.device));
     HIP_OK(hipStreamSynchronize(p->stream));      // (the planner's own stream: other planners are left alone)
     int count = 0;
-    HIP_OK(hipMemcpy(&count, p->d_log_count + planner, 4, hipMemcpyDeviceToHost));
+    HIP_OK(copy_now(&count, p->d_log_count + planner, 4, hipMemcpyDeviceToHost, p->stream));
     const int row = p->nq + 2 * p->nv + 7;
     const double* ring = p->d_log + (size_t)planner * MPPI_LOG_CAP * row;
     int n = count < MPPI_LOG_CAP ? count : MPPI_LOG_CAP;
@@ -836,9 +849,9 @@ int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_ro
     if (n > 0) {
         const int first = (count - n) % MPPI_LOG_CAP;
         const int head = n < MPPI_LOG_CAP - first ? n : MPPI_LOG_CAP - first;
-        HIP_OK(hipMemcpy(rows, ring + (size_t)first * row, (size_t)head * row * 8, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(rows, ring + (size_t)first * row, (size_t)head * row * 8, hipMemcpyDeviceToHost, p->stream));
         if (head < n)
-            HIP_OK(hipMemcpy(rows + (size_t)head * row, ring, (size_t)(n - head) * row * 8, hipMemcpyDeviceToHost));
+            HIP_OK(copy_now(rows + (size_t)head * row, ring, (size_t)(n - head) * row * 8, hipMemcpyDeviceToHost, p->stream));
     }
     *n_rows = n;
     if (total) *total = count;
@@ -1265,10 +1278,10 @@ int mppi_synchronize(mppi_planner* p) try {
 
 static int read_as_double(mppi_planner* p, const void* dsrc, size_t n, double* dst) {
     if (p->cfg.dtype == MPPI_F64) {
-        HIP_OK(hipMemcpy(dst, dsrc, n * 8, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(dst, dsrc, n * 8, hipMemcpyDeviceToHost, p->stream));
     } else {
         std::vector<float> tmp(n);
-        HIP_OK(hipMemcpy(tmp.data(), dsrc, n * 4, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(tmp.data(), dsrc, n * 4, hipMemcpyDeviceToHost, p->stream));
         for (size_t i = 0; i < n; i++) dst[i] = (double)tmp[i];
     }
     return 0;
@@ -1287,13 +1300,13 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) try {
         return read_as_double(p, p->d_R, P * K, (double*)dst);
     case MPPI_READ_ACT_SEQ:
         if (!need(P * HM * 8)) return fail(-1, "ACT_SEQ needs P*H*M doubles");
-        HIP_OK(hipMemcpy(dst, p->d_base, P * HM * 8, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(dst, p->d_base, P * HM * 8, hipMemcpyDeviceToHost, p->stream));
         return 0;
     case MPPI_READ_ARGMAX:
     case MPPI_READ_RMAX: {
         if (!need(P * 8)) return fail(-1, "ARGMAX / RMAX need P values");
         std::vector<double> r(2 * P);
-        HIP_OK(hipMemcpy(r.data(), p->d_result, 16 * P, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(r.data(), p->d_result, 16 * P, hipMemcpyDeviceToHost, p->stream));
         for (size_t b = 0; b < P; b++) {
             if (what == MPPI_READ_ARGMAX) ((int64_t*)dst)[b] = (int64_t)r[2 * b + 1];
             else ((double*)dst)[b] = r[2 * b];
@@ -1305,7 +1318,7 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) try {
         std::vector<double> e(P * HM * K), base(P * HM);
         int rc = read_as_double(p, p->d_eps, P * HM * K, e.data());
         if (rc) return rc;
-        HIP_OK(hipMemcpy(base.data(), p->d_base, P * HM * 8, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(base.data(), p->d_base, P * HM * 8, hipMemcpyDeviceToHost, p->stream));
         double* o = (double*)dst;
         const bool explicit_act = p->explicit_act != 0, f32 = p->cfg.dtype == MPPI_F32;
         // device layout [step, dimension][sample] -> (sample, step, dimension), in tiles of 64 samples so that reads run
@@ -1357,15 +1370,15 @@ int mppi_read(mppi_planner* p, int32_t what, void* dst, size_t bytes) try {
         return read_as_double(p, p->d_rew, P * K * H, (double*)dst);
     case MPPI_READ_STATUS:
         if (!need(4)) return fail(-1, "STATUS needs one int32");
-        HIP_OK(hipMemcpy(dst, p->d_status, 4, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(dst, p->d_status, 4, hipMemcpyDeviceToHost, p->stream));
         return 0;
     case MPPI_READ_STATUS_DETAIL:
         if (!need(16)) return fail(-1, "STATUS_DETAIL needs four int32");
-        HIP_OK(hipMemcpy(dst, p->d_status, 16, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(dst, p->d_status, 16, hipMemcpyDeviceToHost, p->stream));
         return 0;
     case MPPI_READ_PARTIALS:
         if (!need(P * (3 + HM) * 8)) return fail(-1, "PARTIALS needs P*(3+H*M) doubles");
-        HIP_OK(hipMemcpy(dst, p->d_part, P * (3 + HM) * 8, hipMemcpyDeviceToHost));
+        HIP_OK(copy_now(dst, p->d_part, P * (3 + HM) * 8, hipMemcpyDeviceToHost, p->stream));
         return 0;
     }
     return fail(-1, "unknown read selector");
@@ -1483,7 +1496,7 @@ int mppi_comm_init(mppi_planner* p, const void* id, size_t bytes, int32_t rank, 
         p->comm = nullptr; p->comm_rank = 0; p->comm_nranks = 0;
         p->cfg_gen++;
     };
-    hipError_t he = hipMemset(p->d_gathered, 0, row * nranks * 8);
+    hipError_t he = zero_now(p->d_gathered, row * nranks * 8, p->stream);
     if (he != hipSuccess) { undo(); return fail(-2, std::string("hipMemset of the gathered rows: ") + hipGetErrorString(he)); }
     p->d_part_alloc = p->d_part;
     p->d_part = p->d_gathered + row * rank;       // the statistics kernel writes where the gather expects them
@@ -1508,14 +1521,19 @@ int mppi_update_from_returns(int32_t device, const double* act, const double* R,
         double* p = nullptr;
         ~Owned() { if (p) (void)hipFree(p); }
     } d_act, d_R, d_out;
+    struct OwnStream {        // a stream of this call's own (see copy_now)
+        hipStream_t s = nullptr;
+        ~OwnStream() { if (s) (void)hipStreamDestroy(s); }
+    } us;
+    HIP_OK(hipStreamCreateWithFlags(&us.s, hipStreamNonBlocking));
     HIP_OK(hipMalloc(&d_act.p, (size_t)K * HM * 8));
     HIP_OK(hipMalloc(&d_R.p, (size_t)K * 8));
     HIP_OK(hipMalloc(&d_out.p, (size_t)HM * 8));
-    HIP_OK(hipMemcpy(d_act.p, act, (size_t)K * HM * 8, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_R.p, R, (size_t)K * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(update_direct_kernel, dim3(HM), dim3(256), 0, 0, d_act.p, d_R.p, K, (int)HM, kappa, d_out.p);
+    HIP_OK(copy_now(d_act.p, act, (size_t)K * HM * 8, hipMemcpyHostToDevice, us.s));
+    HIP_OK(copy_now(d_R.p, R, (size_t)K * 8, hipMemcpyHostToDevice, us.s));
+    hipLaunchKernelGGL(update_direct_kernel, dim3(HM), dim3(256), 0, us.s, d_act.p, d_R.p, K, (int)HM, kappa, d_out.p);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpy(act_seq_out, d_out.p, (size_t)HM * 8, hipMemcpyDeviceToHost));
+    HIP_OK(copy_now(act_seq_out, d_out.p, (size_t)HM * 8, hipMemcpyDeviceToHost, us.s));
     return 0;
 } catch (const std::exception& e) {
     return fail(-8, std::string("host exception: ") + e.what());

@@ -621,3 +621,37 @@ def test_planners_driven_from_several_host_threads():
     for i in range(len(specs)):
         assert threaded[i][1] == serial[i][1] == 0
         assert np.array_equal(threaded[i][0], serial[i][0]), i
+
+
+def test_agents_driven_from_several_host_threads():
+    """Three `MPPI` agents (own environment, own planner; the compiled model handle is shared) trained step by step in
+    three threads at once give the trajectories they give one after the other -- device noise, host noise, a critic."""
+    import threading
+    import torch
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    from trajopt.models.critic_nets import Critic
+    torch.manual_seed(0)
+    critic = Critic(input_dim=14)
+    specs = [("philox", "f32", None, 512), ("host", "f64", None, 64), ("philox", "f64", critic, 128)]
+
+    def run(spec, out, idx):
+        noise, dtype, c, K = spec
+        e = get_environment('reacher_7dof', reward_type='sparse' if idx == 2 else 'dense')
+        e.reset_model(seed=idx, goal=(0.05 * idx, 0.0, 0.1))
+        ag = MPPI(e, H=10, paths_per_cpu=K, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=3 + idx, noise=noise, dtype=dtype)
+        for _ in range(40):
+            ag.train_step(critic=c, niter=2)
+        out[idx] = (np.array([s["qp"] for s in ag.sol_state]), np.array(ag.sol_reward), ag.act_sequence.copy())
+
+    serial, threaded = {}, {}
+    for i, spec in enumerate(specs):
+        run(spec, serial, i)
+    threads = [threading.Thread(target=run, args=(spec, threaded, i)) for i, spec in enumerate(specs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(len(specs)):
+        for a, b in zip(threaded[i], serial[i]):
+            assert np.array_equal(a, b), i

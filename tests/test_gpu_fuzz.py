@@ -45,8 +45,8 @@ def test_random_walk_over_the_entry_points(dtype, walk):
     from trajopt_amd.device import DeviceModel
     dm = DeviceModel.get("reacher_7dof")
     rs = np.random.RandomState(1000 * walk + (dtype == "f32"))
-    K = int(rs.choice([40, 64, 200, 4096]))
-    H = int(rs.choice([4, 9, 16]))
+    K = int(rs.choice([1, 8, 40, 63, 64, 65, 200, 4096]))
+    H = int(rs.choice([1, 2, 4, 9, 16]))
     default_act = str(rs.choice(["mean", "repeat"]))
     seed = int(rs.randint(1, 10 ** 6))
     # every third walk drives a handle of three planners (own states, own noise planes, own logs)

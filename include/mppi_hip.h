@@ -230,6 +230,8 @@ int mppi_shift(mppi_planner* p, const double* override_seq_HxM, void* stream);
  * in fp64 from the planner's own start state with act_sequence[0], stores the new state as the
  * next start state (timestep + 1), appends a row [qpos', qvel', hand, target, reward, action]
  * (3M+7 doubles) to a ring of MPPI_LOG_CAP rows, and shifts the horizon.  No host round trip.
+ * Horizons up to H * M = 4096 (the shifted sequence travels through registers of one block); longer ones return -1 from
+ * mppi_advance, mppi_advance_noise and mppi_plan, and their callers step with mppi_env_step and mppi_shift instead.
  * mppi_read_log copies the most recent rows (oldest first); total = rows ever written. */
 int mppi_advance(mppi_planner* p, void* stream);
 /* nsteps whole planning steps -- the loop `for t: agent.train_step(niter)` of the example scripts

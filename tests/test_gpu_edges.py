@@ -369,3 +369,23 @@ def test_diverged_rollouts_take_no_part_in_the_update(dm, oracle_sim, dtype):
     p.rollout()
     assert p.status() == 0
     p.close()
+
+
+@pytest.mark.gpu
+def test_horizons_beyond_the_device_resident_advance():
+    """The device-resident advance serves H * m <= 4096; the class takes the separate-launch route for longer
+    horizons (the reference has no limit), the C ABI says -1."""
+    from trajopt.algos.mppi import MPPI
+    from trajopt.envs.utils import get_environment
+    from trajopt_amd._lib import MppiError
+    for noise in ("philox", "host"):
+        e = get_environment('reacher_7dof')
+        e.reset_model(seed=1, goal=(0, 0, 0))
+        ag = MPPI(e, H=600, paths_per_cpu=64, kappa=25.0, filter_coefs=FILTER, default_act='mean', seed=1, noise=noise)
+        assert not ag._real_env_steps_on_the_device()
+        for _ in range(2):
+            ag.train_step(niter=1)
+        assert len(ag.sol_state) == 3 and ag.act_sequence.shape == (600, 7) and np.isfinite(ag.act_sequence).all()
+        assert np.array_equal(ag.act_sequence[-1], np.zeros(7))
+        with pytest.raises(MppiError):
+            ag._planner.plan(1, 1, 1)

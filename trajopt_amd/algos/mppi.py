@@ -182,6 +182,8 @@ class MPPI(Trajectory):
         e = self.env
         if type(e) is not Reacher7DOFEnv:
             return False
+        if self.H * self.m > 4096:           # the advance kernel holds the shifted sequence in registers: 16 values x 256 threads
+            return False
         rt, reference = rollout_objective(e.env_name, self.reward_type, self.reference)
         if self._env_reward() in ('tracking', 'cooling'):
             if rt not in ('tracking', 'cooling') or e.reference is None or reference is None:

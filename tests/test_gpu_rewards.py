@@ -188,9 +188,13 @@ def test_end_of_the_reference_through_the_c_abi(dm):
     p = DevicePlanner(dm, 64, H, kappa=25.0, sigma=FILTER[0], betas=FILTER[1:], default_act="mean", reward_type="tracking",
                       dtype="f64")
     p.set_params(25.0, 1.0, "tracking")
-    p.set_reference(ref, 1.0)
     p.set_base_actions(np.zeros((H, 7)))
     p.set_start_state(np.zeros(7), np.zeros(7), np.zeros(3), 0)
+    # no reference yet: indexing None is a TypeError in the reference; here every rolling entry point says -1
+    for call in (lambda: lib.mppi_plan(p._h, 3, 1, 1, None), lambda: lib.mppi_rollout(p._h, None),
+                 lambda: lib.mppi_iterate(p._h, 1, None), lambda: lib.mppi_advance(p._h, None)):
+        assert call() == -1 and b"needs a reference" in lib.mppi_last_error()
+    p.set_reference(ref, 1.0)
     # time steps 0 .. 5 can be planned: the last index used is 5 + 6 = 11
     assert lib.mppi_plan(p._h, 3, 1, 6, None) == 0
     p.synchronize()

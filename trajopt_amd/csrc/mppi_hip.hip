@@ -401,7 +401,8 @@ static int reference_covers(const mppi_planner* p, int steps, int reward_type) {
     if (e && e[0] == '1') return 0;
     for (int b = 0; b < p->P; b++) {
         const DevState& st = (*p->h_state)[b];
-        if (st.ref_len > 0 && st.timestep + steps >= st.ref_len)
+        if (st.ref_len <= 0) return fail(-1, "tracking / cooling reward needs a reference (mppi_set_reference)");
+        if (st.timestep + steps >= st.ref_len)
             return fail(-5, "reference index out of range: time step " + std::to_string(st.timestep) + " + " +
                                 std::to_string(steps) + " steps, reference of " + std::to_string(st.ref_len) + " rows");
     }

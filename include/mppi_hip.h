@@ -256,7 +256,8 @@ int mppi_read_log(mppi_planner* p, int32_t planner, double* rows, int32_t max_ro
 /* What one `MPPI.train_step` hands back to its caller (trajopt/algos/mppi.py:74-89), after mppi_advance,
  * mppi_advance_noise or mppi_plan: the newest log row of every planner (P x (3M+7) doubles, layout as in
  * mppi_advance) and the shifted act_sequence (P x H*M doubles).  Either pointer may be NULL.
- * A single planner (P = 1) whose newest step was a lone advance or a single step of mppi_plan gets them without a copy:
+ * A single planner (P = 1) whose newest step was a lone advance or a single step of mppi_plan gets them without a copy
+ * from its second read-back on (the first one tells the library that steps are read back):
  * that step's kernel also writes both, and then the count of steps logged, into page-locked host memory of the planner,
  * and this call only waits for the count (it looks at the stream now and then, so a launch that failed cannot hang
  * it).  Every other case (batched planners, the last step inside a multi-step replay, act_sequence changed since by

@@ -318,6 +318,7 @@ struct mppi_planner {
     double* d_mirror;
     uint64_t advances;     // real-env steps enqueued so far (= the count the device will have logged after them) ...
     uint64_t mirror_at;    // ... and the value of that count after the last step that was asked to write the mirror
+    bool mirror_wanted;    // somebody reads steps back (mppi_read_step has been called): single steps write the mirror
     hipStream_t adv_stream;        // stream the last advance was enqueued on
     int* d_next_step;      // [P] index of the planning step after the one being rolled out
     uint32_t* d_noise_key; // [P][2] stream key the Philox noise in d_eps was drawn with (written by the noise kernels)
@@ -467,10 +468,10 @@ extern "C" {
 
 // Bookkeeping of the host mirror (see mppi_planner::h_mirror): an enqueued real-env step that was asked to write it
 // makes it current; anything else that changes act_sequence on the device makes it stale.
-static double* mirror_for(mppi_planner* p, bool wanted) { return (wanted && p->P == 1) ? p->d_mirror : nullptr; }
+static double* mirror_for(mppi_planner* p, bool wanted) { return (wanted && p->mirror_wanted && p->P == 1) ? p->d_mirror : nullptr; }
 static void advanced(mppi_planner* p, int steps, bool last_wrote_mirror, hipStream_t s) {
     p->advances += (uint64_t)steps;
-    p->mirror_at = (last_wrote_mirror && p->P == 1 && p->d_mirror) ? p->advances : 0;
+    p->mirror_at = (last_wrote_mirror && p->mirror_wanted && p->P == 1 && p->d_mirror) ? p->advances : 0;
     p->adv_stream = s;
     for (DevState& st : *p->h_state) st.timestep += steps;
 }
@@ -1197,6 +1198,9 @@ int mppi_read_step(mppi_planner* p, double* rows, double* act_seq) try {
         if (act_seq) std::memcpy(act_seq, p->h_mirror + nrow, nseq * 8);
         return 0;
     }
+    // The first read-back of a planner says that its caller reads steps back: from now on single steps write the
+    // mirror (a captured step is captured again for that; callers that never read pay nothing for it).
+    if (p->h_mirror && !p->mirror_wanted) { p->mirror_wanted = true; p->cfg_gen++; }
     // two small copies into page-locked memory behind whatever the stream of the last step still holds, one wait
     hipStream_t s = p->adv_stream ? p->adv_stream : p->stream;
     if (rows) HIP_OK(hipMemcpyAsync(p->h_step, p->d_last_row, nrow * 8, hipMemcpyDeviceToHost, s));

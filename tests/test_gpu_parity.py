@@ -368,13 +368,17 @@ def test_device_resident_advance_matches_host_driven_loop(dev_model, oracle_sim)
     assert np.abs(q2 - log["qpos"][-1]).max() < 1e-10 and abs(r2 - log["reward"][-1]) < 1e-10
 
 
-@pytest.mark.parametrize("P,K", [(1, 4097), (1, 5000), (3, 4608), (2, 9001)])
-def test_update_with_many_samples_per_planner(dev_model, P, K):
-    """Beyond 4096 samples a planner's weights are evaluated once by their own kernel and the row blocks stream them:
-    ragged sample counts, several planners per handle, statistics of a shard, all against the numpy update."""
-    H = 6
+@pytest.mark.parametrize("P,K,H,dtype", [(1, 4097, 6, "f64"), (1, 5000, 6, "f64"), (3, 4608, 6, "f64"), (2, 9001, 6, "f64"),
+                                          (1, 70001, 64, "f64"), (1, 65536, 64, "f32"), (1, 8200, 300, "f64"),
+                                          (2, 4352, 1, "f64"), (3, 12345, 100, "f32"), (1, 16384, 37, "f32")])
+def test_update_with_many_samples_per_planner(dev_model, P, K, H, dtype):
+    """Beyond 4096 samples a planner's update is cut into chunks of samples as well as rows (maximum, weights, the
+    chunks' sums, their sum in the order of the chunks): ragged sample counts, chunk counts from 1 to 64, several
+    planners per handle, all against the numpy update on the device's own returns and actions."""
     rs = np.random.RandomState(K)
-    b = _planner(dev_model, K, H, "f64", planners=P)
+    # (fp32 actions are the fp32 sum of base and noise, the update adds the weighted noise to the fp64 base)
+    tol = 1e-12 if dtype == "f64" else 2e-6
+    b = _planner(dev_model, K, H, dtype, planners=P)
     q0 = rs.uniform(-0.3, 0.3, (P, 7)) if P > 1 else rs.uniform(-0.3, 0.3, 7)
     v0 = np.zeros_like(q0)
     tgt = rs.uniform(-0.1, 0.1, (P, 3)) if P > 1 else rs.uniform(-0.1, 0.1, 3)
@@ -390,8 +394,21 @@ def test_update_with_many_samples_per_planner(dev_model, P, K):
         Rp, ap = (R[pl], act[pl]) if P > 1 else (R, act)
         want = ref_mppi.update(ap, Rp, 25.0)
         got = seq[pl] if P > 1 else seq
-        assert np.abs(got - want).max() < 1e-12, (pl, np.abs(got - want).max())
+        assert np.abs(got - want).max() < tol, (pl, np.abs(got - want).max())
         assert (am[pl] if P > 1 else am) == int(np.argmax(Rp))
+    # the sparse reward takes three values: returns repeat, often the best too, and the first of the best is the arg-max
+    b.set_params(25.0, 1.0, "sparse")
+    b.set_base_actions(base)
+    b.generate_noise(12)
+    b.rollout()
+    R, act = b.returns(), b.actions()
+    b.iterate(1)
+    seq, am = b.act_sequence(), b.argmax()
+    for pl in range(P):
+        Rp, ap = (R[pl], act[pl]) if P > 1 else (R, act)
+        assert len(np.unique(Rp)) < K // 4
+        assert (am[pl] if P > 1 else am) == int(np.argmax(Rp))
+        assert np.abs((seq[pl] if P > 1 else seq) - ref_mppi.update(ap, Rp, 25.0)).max() < tol
     b.close()
 
 

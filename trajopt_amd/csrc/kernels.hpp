@@ -844,6 +844,127 @@ __global__ void __launch_bounds__(1024) update_weights_kernel(const T* __restric
     if (blockIdx.x == 0 && tid == 0) { out[K] = bv; out[K + 1] = (double)bi; }
 }
 
+// ---- many samples, few planners (update_in_chunks): the samples are cut into chunks as well as the rows ----
+// Four small launches.  (1) chunk_max: 64 blocks per planner each find the maximum / first arg-max of their stretch
+// of the returns.  (2) chunk_weights: every wave folds those 64 pairs (same pairs, same order: same values in every
+// wave), then the blocks write S_k = exp(kappa (R_k - Rmax)) for their stretch, once.  (3) chunk_sums: block
+// (step t, chunk c) streams chunk c's weights against the NV rows of step t: the weights are read once per NV rows
+// and stay in L2 between the H blocks that share a chunk.  (4) chunk_finish: the chunks' sums are added in the
+// order of the chunks -- whatever order the blocks ran in, the same bits -- and act_sequence is written.
+constexpr int UPDATE_MAX_BLOCKS = 64;
+template <class T>
+__global__ void __launch_bounds__(1024) update_chunk_max_kernel(const T* __restrict__ R, int K, double* __restrict__ maxes) {
+    __shared__ double s_v[16];
+    __shared__ int s_i[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    R += (size_t)blockIdx.y * K; maxes += (size_t)blockIdx.y * 2 * UPDATE_MAX_BLOCKS;
+    const int per = (K + UPDATE_MAX_BLOCKS - 1) / UPDATE_MAX_BLOCKS, lo = blockIdx.x * per, hi = lo + per < K ? lo + per : K;
+    double bv = -DBL_MAX;
+    int bi = INT_MAX;
+    for (int k = lo + tid; k < hi; k += 1024) argmax_combine(bv, bi, return_for_max(R[k]), k);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = shfl_xor_d(bv, m);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) argmax_combine(bv, bi, s_v[w], s_i[w]);
+        maxes[2 * blockIdx.x] = bv; maxes[2 * blockIdx.x + 1] = (double)bi;     // (INT_MAX is exact in a double)
+    }
+}
+template <class T>
+__global__ void __launch_bounds__(1024) update_chunk_weights_kernel(const T* __restrict__ R, int K, double kappa,
+                                                                    const double* __restrict__ maxes, double* __restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    R += (size_t)blockIdx.y * K; out += (size_t)blockIdx.y * (K + 2); maxes += (size_t)blockIdx.y * 2 * UPDATE_MAX_BLOCKS;
+    double bv = maxes[2 * lane];
+    int bi = (int)maxes[2 * lane + 1];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = shfl_xor_d(bv, m);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    const int per = (K + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < K ? lo + per : K;
+    for (int k = lo + tid; k < hi; k += 1024) out[k] = sample_weight(kappa, R[k], bv);
+    if (blockIdx.x == 0 && tid == 0) { out[K] = bv; out[K + 1] = (double)bi; }
+}
+// sums: [P][chunks][HM + 1] -- per chunk the HM weighted sums, then the sum of the chunk's weights
+template <class T, int NV>
+__global__ void __launch_bounds__(256) update_chunk_sums_kernel(const T* __restrict__ eps, const double* __restrict__ weights, int K,
+                                                                 int HM, int per, double* __restrict__ sums) {
+    constexpr int BT = 256;
+    __shared__ double s_v[BT / 64][NV + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * NV, c = blockIdx.y, pl = blockIdx.z;
+    eps += ((size_t)pl * HM + row0) * K; weights += (size_t)pl * (K + 2);
+    sums += ((size_t)pl * gridDim.y + c) * (HM + 1);
+    const int lo = c * per, hi = lo + per < K ? lo + per : K;
+    double acc[NV + 1];
+#pragma unroll
+    for (int j = 0; j <= NV; j++) acc[j] = 0.0;
+    constexpr int U = 4;
+    int k = lo + tid;
+    for (; k + (U - 1) * BT < hi; k += U * BT) {
+        double sk[U];
+        T e[NV][U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            sk[u] = weights[k + u * BT];
+#pragma unroll
+            for (int j = 0; j < NV; j++) e[j][u] = eps[(size_t)j * K + k + u * BT];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc[j] = fma(sk[u], (double)e[j][u], acc[j]);
+            acc[NV] += sk[u];
+        }
+    }
+    for (; k < hi; k += BT) {
+        const double sk = weights[k];
+#pragma unroll
+        for (int j = 0; j < NV; j++) acc[j] = fma(sk, (double)eps[(size_t)j * K + k], acc[j]);
+        acc[NV] += sk;
+    }
+#pragma unroll
+    for (int j = 0; j <= NV; j++) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[j] += shfl_xor_d(acc[j], m);
+        if (lane == 0) s_v[wave][j] = acc[j];
+    }
+    __syncthreads();
+    if (tid <= NV) {
+        double tot = 0.0;
+        for (int w = 0; w < BT / 64; w++) tot += s_v[w][tid];
+        if (tid < NV) sums[row0 + tid] = tot;
+        else if (blockIdx.x == 0) sums[HM] = tot;
+    }
+}
+static __global__ void __launch_bounds__(256) update_chunk_finish_kernel(const double* __restrict__ sums, const double* __restrict__ weights,
+                                                                  int K, int HM, int chunks, int k_offset, int write_base,
+                                                                  double* __restrict__ base, double* __restrict__ part,
+                                                                  double* __restrict__ result) {
+    const int hm = blockIdx.x * 256 + threadIdx.x, pl = blockIdx.y;
+    sums += (size_t)pl * chunks * (HM + 1); weights += (size_t)pl * (K + 2);
+    base += (size_t)pl * HM; part += (size_t)pl * (3 + HM); result += 2 * pl;
+    double d = 0.0, n = 0.0;
+    for (int c = 0; c < chunks; c++) d += sums[(size_t)c * (HM + 1) + HM];
+    if (hm < HM) {
+        for (int c = 0; c < chunks; c++) n += sums[(size_t)c * (HM + 1) + hm];
+        if (write_base) base[hm] = (base[hm] * d + n) / (d + 1e-6);
+        part[3 + hm] = n;
+    }
+    if (hm == 0) {
+        const double bv = weights[K];
+        const int bi = (int)weights[K + 1], best = bi == INT_MAX ? 0 : bi;
+        part[0] = bv; part[1] = (double)(k_offset + best); part[2] = d;
+        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + best); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-model dispatch
 // ------------------------------------------------------------------------------------------
@@ -1028,12 +1149,47 @@ static hipError_t launch_critic(int dtype, const void* fobs, int K, int P, int d
 // ... and so are they for batched planners, whose update has one block per step: H blocks would evaluate the same K
 // exponentials each
 inline bool update_wants_weights(int K, int H, int P) { return (K > 4096 && (long)H * P < 1024) || ((long)H * P >= 1024 && K >= 64); }
-// weights: scratch of P * (K + 2) doubles for update_weights_kernel, or null (every block evaluates the weights itself)
+// many samples, few planners: rows x chunks of samples (update_chunk_*_kernel)
+inline bool update_in_chunks(int K, int H, int P) { return K > 4096 && (long)H * P < 1024; }
+inline int update_chunks(int K, int H, int P) {
+    // One block per CU, four waves each: measured best from 8192 to 524288 samples.  (More and larger blocks finish
+    // this kernel no sooner, and a grid of 1024-thread blocks that takes several rounds leaves the next rollout of
+    // one wave per SIMD half as slow again: 65536 samples, 285 -> 470 us.)
+    long c = (256 + (long)H * P - 1) / ((long)H * P);
+    if (c > K / 256) c = K / 256;                           // a chunk gives every thread of its block a sample
+    return (int)(c < 1 ? 1 : (c > 64 ? 64 : c));
+}
+// the update's scratch, in doubles: [P][K + 2] weights, Rmax, arg-max; chunked: then [P][64][2] the stretches' maxima
+// and [P][chunks][HM + 1] the chunks' sums
+inline size_t update_scratch_doubles(int K, int H, int P, int NV) {
+    size_t n = (size_t)P * ((size_t)K + 2);
+    if (update_in_chunks(K, H, P)) n += (size_t)P * 2 * UPDATE_MAX_BLOCKS + (size_t)P * update_chunks(K, H, P) * ((size_t)H * NV + 1);
+    return n;
+}
+// weights: scratch of update_scratch_doubles(K, H, P, NV) doubles, or null (every block evaluates the weights itself)
 template <class MD>
 static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, int K, int H, int P, double kappa, int k_offset,
                                      int write_base, double* weights, double* base, double* part, double* result, hipStream_t s) {
     constexpr int NV = MD::NV;
     const int HM = H * NV;
+    if (weights && update_in_chunks(K, H, P)) {
+        const int chunks = update_chunks(K, H, P), per = (K + chunks - 1) / chunks;
+        double* maxes = weights + (size_t)P * ((size_t)K + 2);
+        double* sums = maxes + (size_t)P * 2 * UPDATE_MAX_BLOCKS;
+        const dim3 mgrid(UPDATE_MAX_BLOCKS, P), sgrid(H, chunks, P), fgrid((HM + 255) / 256, P);
+        if (dtype == MPPI_F32) {
+            hipLaunchKernelGGL((update_chunk_max_kernel<float>), mgrid, dim3(1024), 0, s, (const float*)R, K, maxes);
+            hipLaunchKernelGGL((update_chunk_weights_kernel<float>), mgrid, dim3(1024), 0, s, (const float*)R, K, kappa, maxes, weights);
+            hipLaunchKernelGGL((update_chunk_sums_kernel<float, NV>), sgrid, dim3(256), 0, s, (const float*)eps, weights, K, HM, per, sums);
+        } else {
+            hipLaunchKernelGGL((update_chunk_max_kernel<double>), mgrid, dim3(1024), 0, s, (const double*)R, K, maxes);
+            hipLaunchKernelGGL((update_chunk_weights_kernel<double>), mgrid, dim3(1024), 0, s, (const double*)R, K, kappa, maxes, weights);
+            hipLaunchKernelGGL((update_chunk_sums_kernel<double, NV>), sgrid, dim3(256), 0, s, (const double*)eps, weights, K, HM, per, sums);
+        }
+        hipLaunchKernelGGL(update_chunk_finish_kernel, fgrid, dim3(256), 0, s, sums, weights, K, HM, chunks, k_offset, write_base, base,
+                           part, result);
+        return hipGetLastError();
+    }
     const dim3 block(K > 1024 ? 1024 : 256);
     // enough blocks to spread over the GPU: one per step once there are many planners, else one per entry
 #define MPPI_LAUNCH_UPDATE(ROWS_)                                                                                               \

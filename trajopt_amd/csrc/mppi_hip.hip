@@ -295,7 +295,7 @@ struct mppi_planner {
     hipEvent_t ev_raw_free;        // recorded on the planner's stream behind the last kernel that read d_raw
     hipEvent_t ev_upload_done;     // recorded on copy_stream behind the last piece of a streamed upload
     bool raw_pending;              // d_raw holds (or is receiving) draws that mppi_commit_noise has not filtered yet
-    double* d_weights;     // [P][K + 2] the update's weights, Rmax, arg-max: large K only (update_wants_weights)
+    double* d_weights;     // the update's scratch (update_scratch_doubles): weights, Rmax, arg-max, ...: large K only
     double* d_ref;
     int ref_cap;
     void* d_R;             // T [K]
@@ -431,7 +431,8 @@ static int planner_allocate(mppi_planner* p) {
     HIP_OK(zero_now(p->d_part, (3 * P + HM) * 8, p->stream));
     HIP_OK(hipMalloc(&p->d_result, 2 * 8 * P));
     HIP_OK(zero_now(p->d_result, 2 * 8 * P, p->stream));
-    if (update_wants_weights(cfg->K, cfg->H, (int)P)) HIP_OK(hipMalloc(&p->d_weights, P * ((size_t)cfg->K + 2) * 8));
+    if (update_wants_weights(cfg->K, cfg->H, (int)P))
+        HIP_OK(hipMalloc(&p->d_weights, update_scratch_doubles(cfg->K, cfg->H, (int)P, p->nv) * 8));
     HIP_OK(hipMalloc(&p->d_status, 16));
     HIP_OK(zero_now(p->d_status, 16, p->stream));
     HIP_OK(hipMalloc(&p->d_log, P * MPPI_LOG_CAP * (p->nq + 2 * p->nv + 7) * 8));

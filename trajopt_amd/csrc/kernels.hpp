@@ -192,7 +192,7 @@ __device__ __forceinline__ bool nonfinite(double x) {
 template <class T, class MD, bool LEAN>
 __global__ void __launch_bounds__(256)       // launched with 64 or 256 threads (launch_rollout)
 rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base, const T* __restrict__ eps,
-               const double* __restrict__ ref, int K, int H, int reward_type_, double gamma, int explicit_act_,
+               const double* __restrict__ ref, int K, int H, int P, int reward_type_, double gamma, int explicit_act_,
                T* __restrict__ R, T* __restrict__ obs_, T* __restrict__ rew_, int* __restrict__ status,
                T* __restrict__ fobs_, int* __restrict__ next_step, int sweep_cap) {
     constexpr int NV = MD::NV, NQ = MD::NQ;
@@ -202,12 +202,20 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
     T* __restrict__ rew = LEAN ? nullptr : rew_;
     T* __restrict__ fobs = LEAN ? nullptr : fobs_;
     constexpr int OD = NQ + NV + 6;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    // The grid is a flat list of waves, planner after planner (64 consecutive samples of one planner each), so that
+    // blocks of four waves are full whatever K is.
+    const int wpp = (K + 63) >> 6;                                   // waves per planner
+    // (the wave's index within the block through readfirstlane: the compiler then knows that the planner, and every
+    // address formed from it, is the same in all lanes and keeps them in scalar registers and scalar loads)
+    const int wv = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int planner = wv / wpp;
+    if (planner >= P) return;
+    const int k = (wv - planner * wpp) * 64 + (threadIdx.x & 63);
     if (k >= K) return;
     // index of the planning step after this one, for a noise generator that runs while the state advances
-    if (k == 0) next_step[blockIdx.y] = st[blockIdx.y].timestep + 1;
-    {   // planner blockIdx.y of a batched handle
-        const size_t pl = blockIdx.y;
+    if (k == 0) next_step[planner] = st[planner].timestep + 1;
+    {   // one planner of a batched handle
+        const size_t pl = planner;
         st += pl; base += pl * H * NV; eps += pl * H * NV * K; R += pl * K;
         if (obs) obs += pl * K * H * OD;
         if (rew) rew += pl * K * H;
@@ -288,7 +296,7 @@ rollout_kernel(const DevState* __restrict__ st, const double* __restrict__ base,
             // the first lane to report leaves where it happened: [1] first sample of the wave, [2] env step, [3] planner
             if (!(before & MPPI_STATUS_SWEEP_CAP) && atomicCAS(status + 1, 0, (k & ~63) + 1) == 0) {
                 status[2] = first_capped_step;
-                status[3] = (int)blockIdx.y;
+                status[3] = planner;
             }
         }
     }
@@ -1061,21 +1069,21 @@ template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArg
     // A wave is 64 consecutive samples of one planner whatever the block size.  Blocks of four waves put one wave on
     // each SIMD of a CU; blocks of one wave are placed SIMD by SIMD by the dispatcher, which after a launch whose grid
     // took several rounds (the batched update) packs them two to a SIMD while other SIMDs idle: 128 planners x 512
-    // samples, 1024 waves for 1024 SIMDs, 0.61 -> 0.39 ms per step with blocks of four.  Not where a planner's last block would be
-    // mostly empty (K = 100: its two waves would share SIMDs 0 and 1 of every CU with all other planners' waves).
-    const int waves = (a.K + 63) / 64;
-    const int bt = (waves % 4 == 0 || waves >= 32) ? 256 : 64;
-    const dim3 grid((a.K + bt - 1) / bt, a.P), block(bt);
-    const size_t lds = 0;
+    // samples, 1024 waves for 1024 SIMDs, 0.61 -> 0.39 ms per step with blocks of four (64 planners x 200 samples, 256
+    // waves: 0.42 -> 0.34 ms).  Up to 64 waves -- the single planner of 4096 samples -- either shape takes the same
+    // time; single waves, spread over CUs and XCDs, stay.
+    const int waves = ((a.K + 63) / 64) * a.P;
+    const int bt = waves > 64 ? 256 : 64;
+    const dim3 grid((waves + bt / 64 - 1) / (bt / 64)), block(bt);
     if (dtype == MPPI_F32 && a.lean)
-        hipLaunchKernelGGL((rollout_kernel<float, MD, true>), grid, block, lds, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step, a.sweep_cap);
+        hipLaunchKernelGGL((rollout_kernel<float, MD, true>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
+                           a.H, a.P, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step, a.sweep_cap);
     else if (dtype == MPPI_F32)
-        hipLaunchKernelGGL((rollout_kernel<float, MD, false>), grid, block, lds, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step, a.sweep_cap);
+        hipLaunchKernelGGL((rollout_kernel<float, MD, false>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,
+                           a.H, a.P, a.reward_type, a.gamma, a.explicit_act, (float*)a.R, (float*)a.obs, (float*)a.rew, a.status, (float*)a.fobs, a.next_step, a.sweep_cap);
     else
-        hipLaunchKernelGGL((rollout_kernel<double, MD, false>), grid, block, lds, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
-                           a.H, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs, a.next_step, a.sweep_cap);
+        hipLaunchKernelGGL((rollout_kernel<double, MD, false>), grid, block, 0, s, a.st, a.base, (const double*)a.eps, a.ref, a.K,
+                           a.H, a.P, a.reward_type, a.gamma, a.explicit_act, (double*)a.R, (double*)a.obs, (double*)a.rew, a.status, (double*)a.fobs, a.next_step, a.sweep_cap);
     return hipGetLastError();
 }
 template <class MD>

@@ -1066,14 +1066,17 @@ template <class MD> static bool model_matches(const mppi_model_desc* d, std::str
 }
 
 template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArgs& a, hipStream_t s) {
-    // A wave is 64 consecutive samples of one planner whatever the block size.  Blocks of four waves put one wave on
-    // each SIMD of a CU; blocks of one wave are placed SIMD by SIMD by the dispatcher, which after a launch whose grid
-    // took several rounds (the batched update) packs them two to a SIMD while other SIMDs idle: 128 planners x 512
-    // samples, 1024 waves for 1024 SIMDs, 0.61 -> 0.39 ms per step with blocks of four (64 planners x 200 samples, 256
-    // waves: 0.42 -> 0.34 ms).  Up to 64 waves -- the single planner of 4096 samples -- either shape takes the same
-    // time; single waves, spread over CUs and XCDs, stay.
+    // A wave is 64 consecutive samples of one planner whatever the block size.  The waves of a block go to SIMDs 0, 1,
+    // ... of one CU: blocks of four put one wave on every SIMD of a CU, blocks of two one on SIMDs 0 and 1.  Blocks of
+    // one wave are placed SIMD by SIMD by the dispatcher, which after a launch whose grid took several rounds (the
+    // batched update) packs them two to a SIMD while other SIMDs idle: 128 planners x 512 samples, 1024 waves for 1024
+    // SIMDs, 0.61 -> 0.39 ms per step with blocks of four; 64 planners x 200, 256 waves, 0.42 -> 0.34 ms with blocks of
+    // two or four.  Up to two waves per CU blocks of two keep the waves spread over all CUs, which the variants that
+    // write their trajectories need (18-DoF tree, 512 waves, observations dumped: 0.71 ms against 0.95 with blocks of
+    // four); beyond that blocks of two would leave SIMDs 2 and 3 idle.  Up to 64 waves -- the single planner of 4096
+    // samples -- every shape takes the same time, and single waves stay.
     const int waves = ((a.K + 63) / 64) * a.P;
-    const int bt = waves > 64 ? 256 : 64;
+    const int bt = waves <= 64 ? 64 : (waves <= 512 ? 128 : 256);
     const dim3 grid((waves + bt / 64 - 1) / (bt / 64)), block(bt);
     if (dtype == MPPI_F32 && a.lean)
         hipLaunchKernelGGL((rollout_kernel<float, MD, true>), grid, block, 0, s, a.st, a.base, (const float*)a.eps, a.ref, a.K,

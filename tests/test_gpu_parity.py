@@ -7,6 +7,8 @@ Tolerances
   fp32 kernels : relative 1e-4 on states and returns at H = 32 (the tolerance the planner
                  is specified to), arg-max index exact
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -410,6 +412,37 @@ def test_update_with_many_samples_per_planner(dev_model, P, K, H, dtype):
         assert (am[pl] if P > 1 else am) == int(np.argmax(Rp))
         assert np.abs((seq[pl] if P > 1 else seq) - ref_mppi.update(ap, Rp, 25.0)).max() < tol
     b.close()
+
+
+@pytest.mark.parametrize("K", [64, 65, 100, 128, 129, 250, 1000])
+def test_update_of_many_planners_with_few_samples(dev_model, K):
+    """Many planners, at most 1024 samples each: a block of the update is cut into sub-blocks of one, two or four waves
+    and each owns a step (H = 30 leaves the last block's sub-blocks idle).  Against the numpy update, planner by
+    planner, and bit for bit against the update that draws the noise again."""
+    P, H = 40, 30
+    rs = np.random.RandomState(K)
+    q0, tgt = rs.uniform(-0.3, 0.3, (P, 7)), rs.uniform(-0.1, 0.1, (P, 3))
+    base = rs.randn(P, H, 7) * 0.1
+    out = []
+    for regen in ("0", "1"):
+        os.environ["MPPI_UPDATE_REGEN"] = regen
+        try:
+            b = _planner(dev_model, K, H, "f64", planners=P)
+            b.set_start_state(q0, np.zeros_like(q0), tgt, np.zeros(P, dtype=np.int32))
+            b.set_base_actions(base)
+            b.generate_noise(5)
+            b.rollout()
+            R, act = b.returns(), b.actions()
+            b.iterate(1)
+            seq, am = b.act_sequence(), b.argmax()
+            out.append(seq)
+            for pl in range(P):
+                assert np.abs(seq[pl] - ref_mppi.update(act[pl], R[pl], 25.0)).max() < 1e-12, (regen, pl)
+                assert am[pl] == int(np.argmax(R[pl]))
+            b.close()
+        finally:
+            os.environ.pop("MPPI_UPDATE_REGEN", None)
+    assert np.array_equal(out[0], out[1])
 
 
 def test_batched_planners_equal_independent_planners(dev_model, oracle_sim):

@@ -852,6 +852,67 @@ __global__ void __launch_bounds__(1024) update_weights_kernel(const T* __restric
     if (blockIdx.x == 0 && tid == 0) { out[K] = bv; out[K + 1] = (double)bi; }
 }
 
+// ---- batched planners, at most 1024 samples each, weights evaluated beforehand (update_weights_kernel) ----
+// With few samples per planner the launch is bound by the number of waves the dispatcher has to start (about a
+// nanosecond each), not by HBM: one block of four waves per step starts 262 144 waves for 1024 planners of 64 samples,
+// three in four of them without a sample (270 us).  Here a block of 256 threads is cut into sub-blocks of W waves
+// (W = 1, 2 or 4: a lane per sample up to 256 samples, then k = u, u + 256, ...) and every sub-block owns a step.
+// Every sum is formed in the order of update_rows_kernel at 256 threads -- a thread's samples in turn, the wave's
+// lanes by the exclusive-or tree, the waves in turn -- so act_sequence comes out the same bit for bit (waves without
+// samples added zeros there).  (Several steps per sub-block, to read a weight once for all of them, were measured:
+// two steps no faster, four slower at every shape from 1024 x 64 to 1024 x 512 -- the registers halve the occupancy.)
+template <class T, int NV, int W>
+__global__ void __launch_bounds__(256) update_steps_kernel(const T* __restrict__ eps, int K, int H, int k_offset, int write_base,
+                                                           double* __restrict__ base, double* __restrict__ part,
+                                                           double* __restrict__ result, const double* __restrict__ weights) {
+    constexpr int SW = 64 * W, NS = 4 / W;
+    __shared__ double s_v[4][NV + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = wave / W, u = tid - sub * SW;
+    const int HM = H * NV, pl = blockIdx.y;
+    const int t = blockIdx.x * NS + sub;                // this sub-block's step (the last block may have idle sub-blocks)
+    const bool mine = t < H;
+    eps += ((size_t)pl * HM + (size_t)(mine ? t : 0) * NV) * K;
+    base += (size_t)pl * HM; part += (size_t)pl * (3 + HM); result += 2 * pl; weights += (size_t)pl * (K + 2);
+    double acc[NV + 1];              // [NV]: sum of the weights
+#pragma unroll
+    for (int j = 0; j <= NV; j++) acc[j] = 0.0;
+    for (int k = u; k < K; k += SW) {
+        const double sk = weights[k];
+        T e[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) e[j] = eps[(size_t)j * K + k];
+#pragma unroll
+        for (int j = 0; j < NV; j++) acc[j] = fma(sk, (double)e[j], acc[j]);
+        acc[NV] += sk;
+    }
+#pragma unroll
+    for (int j = 0; j <= NV; j++) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[j] += shfl_xor_d(acc[j], m);
+        if (lane == 0) s_v[wave][j] = acc[j];
+    }
+    __syncthreads();
+    if (u <= NV) {
+        double tot = 0.0;
+        for (int w = 0; w < W; w++) tot += s_v[sub * W + w][u];
+        s_v[sub * W][u] = tot;             // only thread u of the sub-block reads column u of its other rows
+    }
+    __syncthreads();
+    const double d = s_v[sub * W][NV];
+    if (mine && u < NV) {
+        const double n = s_v[sub * W][u];
+        const int hm = t * NV + u;
+        if (write_base) base[hm] = (base[hm] * d + n) / (d + 1e-6);
+        part[3 + hm] = n;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        const double bv = weights[K];
+        const int bi = (int)weights[K + 1], best = bi == INT_MAX ? 0 : bi;      // (no finite return: none is the best)
+        part[0] = bv; part[1] = (double)(k_offset + best); part[2] = d;
+        if (write_base) { result[0] = bv; result[1] = (double)(k_offset + best); }
+    }
+}
+
 // ---- many samples, few planners (update_in_chunks): the samples are cut into chunks as well as the rows ----
 // Four small launches.  (1) chunk_max: 64 blocks per planner each find the maximum / first arg-max of their stretch
 // of the returns.  (2) chunk_weights: every wave folds those 64 pairs (same pairs, same order: same values in every
@@ -1229,7 +1290,21 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
         else hipLaunchKernelGGL((update_weights_kernel<double>), wgrid, dim3(1024), 0, s, (const double*)R, K, kappa, weights);
         w = weights;
     }
-    if ((long)H * P >= 1024) MPPI_LAUNCH_UPDATE(NV);                        // many planners: one block per step
+    if ((long)H * P >= 1024 && w && K <= 1024) {                            // many planners: a sub-block per step
+#define MPPI_LAUNCH_STEPS(W_)                                                                                                   \
+    do {                                                                                                                        \
+        const dim3 grid((H + 4 / (W_) - 1) / (4 / (W_)), P);                                                                    \
+        if (dtype == MPPI_F32)                                                                                                  \
+            hipLaunchKernelGGL((update_steps_kernel<float, NV, W_>), grid, dim3(256), 0, s, (const float*)eps, K, H, k_offset,  \
+                               write_base, base, part, result, w);                                                             \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((update_steps_kernel<double, NV, W_>), grid, dim3(256), 0, s, (const double*)eps, K, H,          \
+                               k_offset, write_base, base, part, result, w);                                                   \
+    } while (0)
+        if (K <= 64) MPPI_LAUNCH_STEPS(1); else if (K <= 128) MPPI_LAUNCH_STEPS(2); else MPPI_LAUNCH_STEPS(4);
+#undef MPPI_LAUNCH_STEPS
+    }
+    else if ((long)H * P >= 1024) MPPI_LAUNCH_UPDATE(NV);                   // ... of more than 1024 samples: one block per step
     else if ((long)HM * P <= cus) MPPI_LAUNCH_UPDATE(1);
     else if ((long)((HM + 1) / 2) * P <= cus) MPPI_LAUNCH_UPDATE(2);
     else MPPI_LAUNCH_UPDATE(4);

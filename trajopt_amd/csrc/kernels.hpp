@@ -346,7 +346,8 @@ __global__ void __launch_bounds__(64) env_step_kernel(const double* __restrict__
 // Device-resident `advance_time` (trajopt/algos/mppi.py:67-89): lane 0 steps the real environment in fp64 with
 // act_sequence[0] from the planner's own state, appends (q', v', hand, target, reward, action) to the log ring and
 // stores the new state; then the whole block shifts the horizon and fills the tail.
-template <class MD>
+// BT: threads of the block (H * NV <= BT * 16)
+template <class MD, int BT = 256>
 __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st, double* __restrict__ base,
                                               const double* __restrict__ ref, int reward_type, int H, int tail_mode,
                                               const double* __restrict__ mean, double* __restrict__ log, int log_cap,
@@ -354,7 +355,7 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
                                               int* __restrict__ status, double* __restrict__ mirror) {
     constexpr int NV = MD::NV, NQ = MD::NQ;
     constexpr int ROW = NQ + 2 * NV + 7;
-    constexpr int PER = 16;                       // H * NV <= 256 * PER
+    constexpr int PER = 16;                       // H * NV <= BT * PER
     const int tid = threadIdx.x;
     double keep[PER];
     const int HM = H * NV;
@@ -363,7 +364,7 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
     log += (size_t)pl * log_cap * ROW; log_count += pl;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
-        const int i = tid + 256 * u;
+        const int i = tid + BT * u;
         double v = 0.0;
         if (i < HM) {
             const int t = i / NV, j = i - t * NV;
@@ -414,7 +415,7 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; u++) {
-        const int i = tid + 256 * u;
+        const int i = tid + BT * u;
         if (i < HM) base[i] = keep[u];
     }
     // The same outcome -- newest log row, shifted act_sequence, then the number of steps logged -- written to
@@ -424,7 +425,7 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
         if (tid < ROW) mirror[tid] = last_row[(size_t)pl * ROW + tid];       // (written by thread 0 before the barrier)
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const int i = tid + 256 * u;
+            const int i = tid + BT * u;
             if (i < HM) mirror[ROW + i] = keep[u];
         }
         __threadfence_system();
@@ -434,13 +435,13 @@ __device__ __forceinline__ void advance_block(int pl, DevState* __restrict__ st,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-template <class MD>
-__global__ void __launch_bounds__(256) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
-                                                      const double* __restrict__ ref, int reward_type, int H, int tail_mode,
-                                                      const double* __restrict__ mean, double* __restrict__ log, int log_cap,
-                                                      int* __restrict__ log_count, double* __restrict__ last_row,
-                                                      int* __restrict__ status, double* __restrict__ mirror) {
-    advance_block<MD>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status, mirror);
+template <class MD, int BT>
+__global__ void __launch_bounds__(BT) advance_kernel(DevState* __restrict__ st, double* __restrict__ base,
+                                                     const double* __restrict__ ref, int reward_type, int H, int tail_mode,
+                                                     const double* __restrict__ mean, double* __restrict__ log, int log_cap,
+                                                     int* __restrict__ log_count, double* __restrict__ last_row,
+                                                     int* __restrict__ status, double* __restrict__ mirror) {
+    advance_block<MD, BT>(blockIdx.x, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap, log_count, last_row, status, mirror);
 }
 // advance_kernel and, in the blocks behind the first of every planner, the Philox noise of the NEXT planning step
 // (stream key seed + next_step[planner], published by the rollouts of the current step): the noise does not depend
@@ -1191,8 +1192,16 @@ template <class MD>
 static hipError_t launch_advance(DevState* st, double* base, const double* ref, int reward_type, int H, int P, int tail_mode,
                                  const double* mean, double* log, int log_cap, int* log_count, double* last_row, int* status,
                                  double* mirror, hipStream_t s) {
-    hipLaunchKernelGGL((advance_kernel<MD>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log, log_cap,
-                       log_count, last_row, status, P == 1 ? mirror : nullptr);
+    // The fp64 step's registers let a CU hold two blocks of 256 threads: 512 planners a round, each as long as the one
+    // lane that steps the environment takes.  From 512 planners on one wave per planner (1024 planners: 52 -> 33 us,
+    // 512: 28 -> 22 us; four such waves in one block, a wave on every SIMD of a CU, take 31 us at any count: the lanes
+    // that step an environment slow each other down when they share a CU).
+    if (P >= 512 && H * MD::NV <= 64 * 16)
+        hipLaunchKernelGGL((advance_kernel<MD, 64>), dim3(P), dim3(64), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
+                           log_cap, log_count, last_row, status, nullptr);
+    else
+        hipLaunchKernelGGL((advance_kernel<MD, 256>), dim3(P), dim3(256), 0, s, st, base, ref, reward_type, H, tail_mode, mean, log,
+                           log_cap, log_count, last_row, status, P == 1 ? mirror : nullptr);
     return hipGetLastError();
 }
 template <class MD>

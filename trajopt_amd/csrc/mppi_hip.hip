@@ -6,6 +6,8 @@
 //   rollout_kernel<T, MD, LEAN>                 H env steps x FRAME_SKIP substeps, fused reward + discounted return
 //   update_rows_kernel<T, NV, ROWS>             max / arg-max over K, S_k = exp(kappa (R_k - Rmax)), sum S, sum S eps:
 //                                               the whole update of a single rank, or a shard's statistics
+//   update_weights_kernel + update_steps_kernel the same for many planners in one handle (weights once, a sub-block per step)
+//   update_chunk_{max,weights,sums,finish}      the same for one planner of more than 4096 samples (rows x chunks of samples)
 //   merge_kernel                                rank-ordered merge of shard statistics, writes act_sequence
 //   advance_kernel / advance_noise_kernel       fp64 step of the real environment, log, receding-horizon shift
 //                                               (+ the next step's Philox noise on the other blocks)

@@ -312,7 +312,7 @@ def test_random_shapes_of_the_update(case):
     rs = np.random.RandomState(999 + case)
     dm = DeviceModel.get("reacher_7dof")
     H = int(rs.randint(1, 33))
-    P = int(rs.choice([1, 1, 1, 2, 5]))
+    P = int(rs.choice([1, 1, 1, 2, 5, 40, 200]))         # (40 and 200: the batched shapes, a sub-block of waves per step)
     kmax = min(150000, 2_000_000 // (H * P))
     K = int(np.exp(rs.uniform(0, np.log(kmax))))
     kappa = float(rs.choice([0.0, 1.0, 25.0, 300.0]))

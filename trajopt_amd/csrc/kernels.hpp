@@ -60,7 +60,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 }
 
 // ------------------------------------------------------------------------------------------
-// noise kernels: one lane per sample, recursion along t in registers
+// noise kernels: the recursion along t of one (sample, action dimension) in registers
 // eps[t] = b0*sigma*z[t] + b1*eps[t-1] + b2*eps[t-2] for t >= 2 (rows 0, 1 unfiltered); separate
 // roundings for every product and sum so the fp64 path reproduces the host arithmetic bit for bit
 // ------------------------------------------------------------------------------------------
@@ -69,34 +69,87 @@ struct FilterCoefs {
     double b0, b1, b2;
 };
 
+// A block takes 64 samples.  The host's array is sample-major ([K][H][NV] fp64, a sample's draws contiguous), the
+// rollouts want step-major, sample-minor: the block reads TC steps of its 64 samples with consecutive threads on
+// consecutive addresses, turns them through LDS, and lane k of wave w runs the recursion of (sample k, dimensions w,
+// w + 4, ...) along those steps, 64 consecutive samples per store.  (One lane per sample reading its own row took
+// 60 us for 4096 x 64 x 7 draws -- 64 waves, every load a cache line per lane; this shape takes a quarter of that.)
 template <class T, int NV>
-__global__ void __launch_bounds__(64) noise_upload_kernel(const double* __restrict__ raw, int K, int H, FilterCoefs fc,
-                                                          int filter, T* __restrict__ eps) {
+__global__ void __launch_bounds__(256) noise_upload_kernel(const double* __restrict__ raw, int K, int H, FilterCoefs fc,
+                                                           int filter, T* __restrict__ eps) {
     // numpy rounds every product and every sum of the recursion by itself; the compiler must not fuse them (it did:
     // with the reference's usual taps (0.25, 0.8, 0) a fused multiply-add gives the same bits -- 0.25 e is exact, 0 e2
     // vanishes -- so only other coefficients showed the last-bit difference)
 #pragma clang fp contract(off)
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K) return;
+    constexpr int TC = 112 / NV < 16 ? 112 / NV : 16;       // steps per pass through LDS
+    constexpr int ROWW = TC * NV + 1;                        // (+1: lanes of a wave read a column, one bank apart)
+    constexpr int JW = (NV + 3) / 4;                         // dimensions per wave
+    __shared__ double tile[64 * ROWW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * 64, k = k0 + lane;
     raw += (size_t)blockIdx.y * K * H * NV;           // planner blockIdx.y of a batched handle
     eps += (size_t)blockIdx.y * H * NV * K;
-    double e1[NV], e2[NV];
+    double e1[JW], e2[JW], sg[JW];
+    // (sigma of this wave's dimensions once, into registers: indexed by the wave inside the loop it is a load from the
+    // argument block at every step, and the wait for it is a wait for every store and prefetch in flight as well)
 #pragma unroll
-    for (int j = 0; j < NV; j++) e1[j] = e2[j] = 0.0;
-    for (int t = 0; t < H; t++) {
+    for (int jj = 0; jj < JW; jj++) {
+        e1[jj] = e2[jj] = 0.0;
+        sg[jj] = fc.sigma[wave + 4 * jj < NV ? wave + 4 * jj : NV - 1];
+    }
+    // wave w fetches the rows of samples w, w + 4, ...; the loads of the next pass are in flight while this one is
+    // worked through
+    constexpr int PER = (TC * NV + 63) / 64;                 // values of one row per lane
+    double got[16][PER];
+    auto fetch = [&](int tc) {
+        // (every load unconditional, from an address that exists: a load behind a branch is waited for before the next
+        // one is issued.  What lies beyond the sample count or the horizon is fetched from the last sample / step and
+        // never used.)
+        if (tc >= H) tc = 0;
+        const int span = (H - tc < TC ? H - tc : TC) * NV;
 #pragma unroll
-        for (int j = 0; j < NV; j++) {
-            double e = raw[((size_t)k * H + t) * NV + j];
-            if (filter) {
-                // (plain operators: the rounding intrinsics are inline functions compiled with contraction allowed,
-                // which the pragma above cannot reach)
-                e = e * fc.sigma[j];
-                if (t >= 2) e = (fc.b0 * e + fc.b1 * e1[j]) + fc.b2 * e2[j];
+        for (int r = 0; r < 16; r++)
+#pragma unroll
+            for (int c = 0; c < PER; c++) {
+                const int smp = wave + 4 * r, off = lane + 64 * c;
+                const int sk = k0 + smp < K ? k0 + smp : K - 1, so = off < span ? off : span - 1;
+                got[r][c] = raw[((size_t)sk * H + tc) * NV + so];
             }
-            e2[j] = e1[j];
-            e1[j] = e;
-            eps[((size_t)t * NV + j) * K + k] = T(e);
+    };
+    fetch(0);
+    for (int tc = 0; tc < H; tc += TC) {
+        const int nt = H - tc < TC ? H - tc : TC;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+#pragma unroll
+            for (int c = 0; c < PER; c++) {
+                const int smp = wave + 4 * r, off = lane + 64 * c;
+                if (off < TC * NV) tile[smp * ROWW + off] = got[r][c];
+            }
+        __syncthreads();
+        fetch(tc + TC);
+        if (k < K) {
+            for (int u = 0; u < nt; u++) {
+                const int t = tc + u;
+#pragma unroll
+                for (int jj = 0; jj < JW; jj++) {
+                    const int j = wave + 4 * jj;
+                    if (j < NV) {
+                        double e = tile[lane * ROWW + u * NV + j];
+                        if (filter) {
+                            // (plain operators: the rounding intrinsics are inline functions compiled with contraction
+                            // allowed, which the pragma above cannot reach)
+                            e = e * sg[jj];
+                            if (t >= 2) e = (fc.b0 * e + fc.b1 * e1[jj]) + fc.b2 * e2[jj];
+                        }
+                        e2[jj] = e1[jj];
+                        e1[jj] = e;
+                        eps[((size_t)t * NV + j) * K + k] = T(e);
+                    }
+                }
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -1154,7 +1207,7 @@ template <class MD> static hipError_t launch_rollout(int dtype, const RolloutArg
 template <class MD>
 static hipError_t launch_noise_upload(int dtype, const double* raw, int K, int H, int P, const FilterCoefs& fc, int filter, void* eps,
                                       hipStream_t s) {
-    const dim3 grid((K + 63) / 64, P), block(64);
+    const dim3 grid((K + 63) / 64, P), block(256);
     if (dtype == MPPI_F32)
         hipLaunchKernelGGL((noise_upload_kernel<float, MD::NV>), grid, block, 0, s, raw, K, H, fc, filter, (float*)eps);
     else

@@ -707,10 +707,13 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
     if (held) {
 #pragma unroll
         for (int e = 0; e < HOLD; e++) {
-            const int k = tid + e * nthreads;
-            rv[e] = k < K ? R[k] : T(0);
+            // (every load unconditional, from an address that exists -- a load behind a bounds test is waited for
+            // before the next one is issued, twelve round trips instead of one; what a sample or row beyond the end
+            // fetches is never used)
+            const int k = tid + e * nthreads, kc = k < K ? k : K - 1;
+            rv[e] = R[kc];
 #pragma unroll
-            for (int j = 0; j < ROWS; j++) ev[j][e] = (k < K && j < nr) ? eps[(size_t)j * K + k] : T(0);
+            for (int j = 0; j < ROWS; j++) ev[j][e] = eps[(size_t)(j < nr ? j : 0) * K + kc];
         }
     }
     double bv = -DBL_MAX;
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
                 if (weights) sk[u] = weights[k + u * nthreads];
                 else ru[u] = R[k + u * nthreads];
 #pragma unroll
-                for (int j = 0; j < ROWS; j++) e[j][u] = j < nr ? eps[(size_t)j * K + k + u * nthreads] : T(0);
+                for (int j = 0; j < ROWS; j++) e[j][u] = eps[(size_t)(j < nr ? j : 0) * K + k + u * nthreads];
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {

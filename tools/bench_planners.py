@@ -27,9 +27,17 @@ for P in [int(x) for x in (sys.argv[1:] or ["128", "1024"])]:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms, n = p.profile_read()
+    # the same steps as one call (captured graphs, eight steps per replay; no events around the rollouts)
+    p.profile(False)
+    p.plan(1000, 1, 8, s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    p.plan(1000, 1, 4 * steps, s)
+    torch.cuda.synchronize()
+    dt_plan = (time.perf_counter() - t0) / (4 * steps)
     d = [float(np.linalg.norm(p.read_log(planner=b)["hand"][-1] - tgt[b])) for b in (0, P // 2, P - 1)]
-    print(json.dumps({"planners": P, "K": K, "H": H, "ms_per_step": 1e3 * dt / steps, "rollout_ms": ms / n,
+    print(json.dumps({"planners": P, "K": K, "H": H, "ms_per_step": 1e3 * dt / steps, "ms_per_step_one_call": 1e3 * dt_plan, "rollout_ms": ms / n,
                       "planner_steps_per_s": P * steps / dt, "env_steps_per_s": P * K * H * steps / dt,
                       "rollout_frac_fp32_valu": FLOP * P * K * H / (ms / n) / 1e9 / 157.3,
-                      "hand_target_dist_after_%d_steps" % (steps + 3): d}), flush=True)
+                      "hand_target_dist_after_%d_steps" % (5 * steps + 11): d}), flush=True)
     p.close()

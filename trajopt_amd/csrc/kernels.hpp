@@ -815,9 +815,9 @@ __global__ void __launch_bounds__(1024) update_rows_kernel(const T* __restrict__
 // The update of batched planners without reading the noise back: a block owns one action dimension j of one planner
 // and ALL steps; every thread draws the perturbations of its samples again (philox_sequence with the key the noise
 // kernel left behind: the same bits the rollouts read) and keeps one running sum per step.  Each sum is formed in the
-// order update_rows_kernel uses for the same launch shape -- a thread's samples k = tid, tid + blockDim, ... in turn,
-// the wave's lanes by the exclusive-or tree, the waves in turn -- so act_sequence comes out bit for bit as from the
-// stored noise; what changes is the memory traffic (no read of eps: a third of the bytes of a batched planning step).
+// order update_steps_kernel uses -- launched with 64 threads: a lane's samples k = lane, lane + 64, ... in turn, then
+// the lanes by the exclusive-or tree (more threads: the waves' sums in turn after that) -- so act_sequence comes out bit
+// for bit as from the stored noise; what changes is the memory traffic (no read of eps: a third of the bytes of a batched planning step).
 // HT: compile-time bound on the horizon (one fp64 running sum per step in registers).
 template <class T, int NV, int HT>
 __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__ R, int K, int H, double kappa, int k_offset,
@@ -827,6 +827,7 @@ __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__
     __shared__ double s_v[4][HT + 1];
     __shared__ int s_i[4];
     const int j = blockIdx.x, pl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;          // 64 to 256 threads
     const int HM = H * NV;
     R += (size_t)pl * K;
     base += (size_t)pl * HM; part += (size_t)pl * (3 + HM); result += 2 * pl;
@@ -834,7 +835,7 @@ __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__
     // Rmax and the first arg-max, as every block of update_rows_kernel finds them
     double bv = -DBL_MAX;
     int bi = INT_MAX;
-    for (int k = tid; k < K; k += 256) argmax_combine(bv, bi, return_for_max(R[k]), k);
+    for (int k = tid; k < K; k += nthreads) argmax_combine(bv, bi, return_for_max(R[k]), k);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const double ov = shfl_xor_d(bv, m);
@@ -844,12 +845,12 @@ __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__
     if (lane == 0) { s_v[wave][0] = bv; s_i[wave] = bi; }
     __syncthreads();
     bv = s_v[0][0]; bi = s_i[0];
-    for (int w = 1; w < 4; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
+    for (int w = 1; w < nwaves; w++) argmax_combine(bv, bi, s_v[w][0], s_i[w]);
     __syncthreads();
     double acc[HT + 1];              // [HT]: sum of the weights
 #pragma unroll
     for (int t = 0; t <= HT; t++) acc[t] = 0.0;
-    for (int k = tid; k < K; k += 256) {
+    for (int k = tid; k < K; k += nthreads) {
         const double sk = sample_weight(kappa, R[k], bv);
         // (fully unrolled: t is a constant in every call, the running sums stay in registers)
         philox_sequence<HT>((uint32_t)(k_offset + k), j, pl, key_lo, key_hi, H, fc,
@@ -863,14 +864,14 @@ __global__ void __launch_bounds__(256) update_regen_kernel(const T* __restrict__
         if (lane == 0) s_v[wave][t] = acc[t];
     }
     __syncthreads();
-    for (int t = tid; t <= HT; t += 256) {
+    for (int t = tid; t <= HT; t += nthreads) {
         double tot = 0.0;
-        for (int w = 0; w < 4; w++) tot += s_v[w][t];
+        for (int w = 0; w < nwaves; w++) tot += s_v[w][t];
         s_v[0][t] = tot;                   // only this thread reads column t of the other rows
     }
     __syncthreads();
     const double d = s_v[0][HT];
-    for (int t = tid; t < H; t += 256) {
+    for (int t = tid; t < H; t += nthreads) {
         const double n = s_v[0][t];
         if (write_base) base[t * NV + j] = (base[t * NV + j] * d + n) / (d + 1e-6);
         part[3 + t * NV + j] = n;
@@ -912,28 +913,27 @@ __global__ void __launch_bounds__(1024) update_weights_kernel(const T* __restric
 // ---- batched planners, at most 1024 samples each, weights evaluated beforehand (update_weights_kernel) ----
 // With few samples per planner the launch is bound by the number of waves the dispatcher has to start (about a
 // nanosecond each), not by HBM: one block of four waves per step starts 262 144 waves for 1024 planners of 64 samples,
-// three in four of them without a sample (270 us).  Here a block of 256 threads is cut into sub-blocks of W waves
-// (W = 1, 2 or 4: a lane per sample up to 256 samples, then k = u, u + 256, ...) and every sub-block owns a step.
-// Every sum is formed in the order of update_rows_kernel at 256 threads -- a thread's samples in turn, the wave's
-// lanes by the exclusive-or tree, the waves in turn -- so act_sequence comes out the same bit for bit (waves without
-// samples added zeros there).  (Several steps per sub-block, to read a weight once for all of them, were measured:
-// two steps no faster, four slower at every shape from 1024 x 64 to 1024 x 512 -- the registers halve the occupancy.)
-template <class T, int NV, int W>
+// three in four of them without a sample (270 us).  Here every wave owns a step (four steps to a block): lane l sums
+// its samples k = l, l + 64, ... in turn, the lanes are added by the exclusive-or tree, and lanes 0 .. NV - 1 write the
+// step's entries of act_sequence -- no shared memory, no barrier.  update_regen_kernel launched with 64 threads forms
+// its sums in the same order.  Measured against sub-blocks of two and four waves per step (whole step, same box):
+// 1024 planners x 512 samples 2.47 -> 2.36 ms, 256 x 256 0.43 -> 0.38, 128 x 512 0.39 -> 0.38, 66 x 1000 unchanged.
+// (Several steps per wave, to read a weight once for all of them, were measured too: two steps no faster, four slower
+// at every shape -- the registers halve the occupancy.)
+template <class T, int NV>
 __global__ void __launch_bounds__(256) update_steps_kernel(const T* __restrict__ eps, int K, int H, int k_offset, int write_base,
                                                            double* __restrict__ base, double* __restrict__ part,
                                                            double* __restrict__ result, const double* __restrict__ weights) {
-    constexpr int SW = 64 * W, NS = 4 / W;
-    __shared__ double s_v[4][NV + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = wave / W, u = tid - sub * SW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int HM = H * NV, pl = blockIdx.y;
-    const int t = blockIdx.x * NS + sub;                // this sub-block's step (the last block may have idle sub-blocks)
-    const bool mine = t < H;
-    eps += ((size_t)pl * HM + (size_t)(mine ? t : 0) * NV) * K;
+    const int t = blockIdx.x * 4 + wave;                // this wave's step
+    if (t >= H) return;
+    eps += ((size_t)pl * HM + (size_t)t * NV) * K;
     base += (size_t)pl * HM; part += (size_t)pl * (3 + HM); result += 2 * pl; weights += (size_t)pl * (K + 2);
     double acc[NV + 1];              // [NV]: sum of the weights
 #pragma unroll
     for (int j = 0; j <= NV; j++) acc[j] = 0.0;
-    for (int k = u; k < K; k += SW) {
+    for (int k = lane; k < K; k += 64) {
         const double sk = weights[k];
         T e[NV];
 #pragma unroll
@@ -946,23 +946,17 @@ __global__ void __launch_bounds__(256) update_steps_kernel(const T* __restrict__
     for (int j = 0; j <= NV; j++) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) acc[j] += shfl_xor_d(acc[j], m);
-        if (lane == 0) s_v[wave][j] = acc[j];
     }
-    __syncthreads();
-    if (u <= NV) {
-        double tot = 0.0;
-        for (int w = 0; w < W; w++) tot += s_v[sub * W + w][u];
-        s_v[sub * W][u] = tot;             // only thread u of the sub-block reads column u of its other rows
-    }
-    __syncthreads();
-    const double d = s_v[sub * W][NV];
-    if (mine && u < NV) {
-        const double n = s_v[sub * W][u];
-        const int hm = t * NV + u;
+    const double d = acc[NV];
+    double n = 0.0;                   // lane j takes sum j (NV < 64)
+#pragma unroll
+    for (int j = 0; j < NV; j++) n = lane == j ? acc[j] : n;
+    if (lane < NV) {
+        const int hm = t * NV + lane;
         if (write_base) base[hm] = (base[hm] * d + n) / (d + 1e-6);
         part[3 + hm] = n;
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (t == 0 && lane == 0) {
         const double bv = weights[K];
         const int bi = (int)weights[K + 1], best = bi == INT_MAX ? 0 : bi;      // (no finite return: none is the best)
         part[0] = bv; part[1] = (double)(k_offset + best); part[2] = d;
@@ -1235,7 +1229,7 @@ static hipError_t launch_update_regen(int dtype, const void* R, int K, int H, in
                                       double* base, double* part, double* result, const uint32_t* key, const FilterCoefs& fc,
                                       hipStream_t s) {
     constexpr int NV = MD::NV;
-    const dim3 grid(NV, P), block(256);
+    const dim3 grid(NV, P), block(64);           // one wave: the summation order of update_steps_kernel
 #define MPPI_LAUNCH_REGEN(T_, HT_)                                                                                            \
     hipLaunchKernelGGL((update_regen_kernel<T_, NV, HT_>), grid, block, 0, s, (const T_*)R, K, H, kappa, k_offset, write_base, \
                        base, part, result, key, fc)
@@ -1355,19 +1349,14 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
         else hipLaunchKernelGGL((update_weights_kernel<double>), wgrid, dim3(1024), 0, s, (const double*)R, K, kappa, weights);
         w = weights;
     }
-    if ((long)H * P >= 1024 && w && K <= 1024) {                            // many planners: a sub-block per step
-#define MPPI_LAUNCH_STEPS(W_)                                                                                                   \
-    do {                                                                                                                        \
-        const dim3 grid((H + 4 / (W_) - 1) / (4 / (W_)), P);                                                                    \
-        if (dtype == MPPI_F32)                                                                                                  \
-            hipLaunchKernelGGL((update_steps_kernel<float, NV, W_>), grid, dim3(256), 0, s, (const float*)eps, K, H, k_offset,  \
-                               write_base, base, part, result, w);                                                             \
-        else                                                                                                                    \
-            hipLaunchKernelGGL((update_steps_kernel<double, NV, W_>), grid, dim3(256), 0, s, (const double*)eps, K, H,          \
-                               k_offset, write_base, base, part, result, w);                                                   \
-    } while (0)
-        if (K <= 64) MPPI_LAUNCH_STEPS(1); else if (K <= 128) MPPI_LAUNCH_STEPS(2); else MPPI_LAUNCH_STEPS(4);
-#undef MPPI_LAUNCH_STEPS
+    if ((long)H * P >= 1024 && w && K <= 1024) {                            // many planners: a wave per step
+        const dim3 grid((H + 3) / 4, P);
+        if (dtype == MPPI_F32)
+            hipLaunchKernelGGL((update_steps_kernel<float, NV>), grid, dim3(256), 0, s, (const float*)eps, K, H, k_offset, write_base,
+                               base, part, result, w);
+        else
+            hipLaunchKernelGGL((update_steps_kernel<double, NV>), grid, dim3(256), 0, s, (const double*)eps, K, H, k_offset,
+                               write_base, base, part, result, w);
     }
     else if ((long)H * P >= 1024) MPPI_LAUNCH_UPDATE(NV);                   // ... of more than 1024 samples: one block per step
     else if ((long)HM * P <= cus) MPPI_LAUNCH_UPDATE(1);

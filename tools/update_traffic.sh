@@ -19,4 +19,4 @@ run() {   # name, kernel name part, algorithmic bytes, step_breakdown arguments
 # noise H*7*K*4 (+ weights 8 K per step from L2 / returns 4 K)
 run k4096   "update_rows_kernel<float, 7, 2>"      7602176     4096
 run k65536  "update_chunk_sums_kernel<float, 7>"   117964800   65536
-run p1024   "update_steps_kernel<float, 7, 4>"     943718400   512 1024
+run p1024   "update_steps_kernel<float, 7>"        943718400   512 1024

@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(1024) update_weights_kernel(const T* __restric
     if (blockIdx.x == 0 && tid == 0) { out[K] = bv; out[K + 1] = (double)bi; }
 }
 
-// ---- batched planners, at most 1024 samples each, weights evaluated beforehand (update_weights_kernel) ----
+// ---- batched planners, at most 4096 samples each, weights evaluated beforehand (update_weights_kernel) ----
 // With few samples per planner the launch is bound by the number of waves the dispatcher has to start (about a
 // nanosecond each), not by HBM: one block of four waves per step starts 262 144 waves for 1024 planners of 64 samples,
 // three in four of them without a sample (270 us).  Here every wave owns a step (four steps to a block): lane l sums
@@ -1349,7 +1349,9 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
         else hipLaunchKernelGGL((update_weights_kernel<double>), wgrid, dim3(1024), 0, s, (const double*)R, K, kappa, weights);
         w = weights;
     }
-    if ((long)H * P >= 1024 && w && K <= 1024) {                            // many planners: a wave per step
+    // many planners: a wave per step, up to 4096 samples per planner (16 planners x 4096: whole step 386 -> 376 us, 32 x
+    // 2048: 405 -> 369; equal at 8192, and beyond that one wave per step has too few loads in flight: 16 x 65 536 4.6 -> 5.0 ms)
+    if ((long)H * P >= 1024 && w && K <= 4096) {
         const dim3 grid((H + 3) / 4, P);
         if (dtype == MPPI_F32)
             hipLaunchKernelGGL((update_steps_kernel<float, NV>), grid, dim3(256), 0, s, (const float*)eps, K, H, k_offset, write_base,
@@ -1358,7 +1360,7 @@ static hipError_t launch_update_rows(int dtype, const void* R, const void* eps, 
             hipLaunchKernelGGL((update_steps_kernel<double, NV>), grid, dim3(256), 0, s, (const double*)eps, K, H, k_offset,
                                write_base, base, part, result, w);
     }
-    else if ((long)H * P >= 1024) MPPI_LAUNCH_UPDATE(NV);                   // ... of more than 1024 samples: one block per step
+    else if ((long)H * P >= 1024) MPPI_LAUNCH_UPDATE(NV);                   // ... of more than 4096 samples: one block per step
     else if ((long)HM * P <= cus) MPPI_LAUNCH_UPDATE(1);
     else if ((long)((HM + 1) / 2) * P <= cus) MPPI_LAUNCH_UPDATE(2);
     else MPPI_LAUNCH_UPDATE(4);
